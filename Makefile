@@ -1,0 +1,49 @@
+# Build recipe for the host library, the oracle, the HIP library and (in the build
+# container only) the reference pin under oracle/_ref.  No cmake/ninja needed.
+CC      ?= gcc
+HIPCC   ?= /opt/rocm/bin/hipcc
+CFLAGS  ?= -O2 -g -std=gnu11 -fPIC -Wall -Wextra -Wno-unused-parameter
+REF     ?= /root/reference
+
+HOST_SRC = marlin_amd/host/mdict.c marlin_amd/host/mshard.c marlin_amd/host/manalyzer.c \
+           marlin_amd/host/mquery.c marlin_amd/host/mplan.c
+HOST_HDR = $(wildcard marlin_amd/host/*.h) include/marlin_gpu.h
+ORC_SRC  = oracle/orc_squery.c oracle/orc_sort.c
+GPU_SRC  = $(wildcard marlin_amd/csrc/*.hip)
+GPU_HDR  = $(wildcard marlin_amd/csrc/*.h) include/marlin_gpu.h
+
+all: gpu host oracle
+
+gpu: marlin_amd/lib/libmarlin_gpu.so
+host: marlin_amd/lib/libmarlin_host.so
+oracle: oracle/liborc.so
+
+marlin_amd/lib/libmarlin_gpu.so: $(GPU_SRC) $(GPU_HDR)
+	@mkdir -p marlin_amd/lib
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Iinclude -Imarlin_amd/csrc \
+	    -o $@ $(GPU_SRC)
+
+marlin_amd/lib/libmarlin_host.so: $(HOST_SRC) $(HOST_HDR) marlin_amd/lib/libmarlin_gpu.so
+	@mkdir -p marlin_amd/lib
+	$(CC) $(CFLAGS) -shared -Iinclude -o $@ $(HOST_SRC) -Lmarlin_amd/lib -lmarlin_gpu \
+	    -Wl,-rpath,'$$ORIGIN' -lm -lpthread
+
+oracle/liborc.so: $(ORC_SRC) oracle/orc.h $(HOST_HDR) marlin_amd/lib/libmarlin_host.so
+	$(CC) $(CFLAGS) -shared -o $@ $(ORC_SRC) -Lmarlin_amd/lib -lmarlin_host \
+	    -Wl,-rpath,'$$ORIGIN/../marlin_amd/lib' -lm
+
+# The reference's own bitmap / sort / hashtable / farmhash sources, compiled unmodified from
+# where they lie.  Only possible where /root/reference exists (the build container).
+ref: oracle/_ref/libmarlin_ref.so
+oracle/_ref/libmarlin_ref.so:
+	@mkdir -p oracle/_ref
+	$(CC) -std=gnu99 -O2 -fPIC -shared -D_GNU_SOURCE -DH2O_USE_LIBUV=0 \
+	    -I$(REF)/src/inc -I$(REF)/src/main -I$(REF)/src/utils \
+	    -I$(REF)/deps/jansson/src -I$(REF)/deps/jansson/android -I$(REF)/deps/h2o/include \
+	    $(REF)/src/main/bmap.c $(REF)/src/main/cont.c $(REF)/src/main/sort.c \
+	    $(REF)/src/main/hashtable.c $(REF)/src/utils/farmhash-c.c -o $@
+
+clean:
+	rm -f marlin_amd/lib/*.so oracle/liborc.so oracle/_ref/*.so
+
+.PHONY: all gpu host oracle ref clean

@@ -1,0 +1,193 @@
+/* marlin_gpu.h -- C ABI of libmarlin_gpu.so, the MI355X shard-query engine.
+ *
+ * Drop-in boundary for Marlin's per-shard query path.  Marlin itself has no plugin or FFI
+ * interface: the seam is the pair of C symbols in src/main/squery.h:59-60
+ *      void execute_squery(void *w);      void sqresult_free(struct query *, struct squery_result *);
+ * A replacement squery.c keeps those two symbols, turns its `struct squery` into the flat
+ * `mgpu_plan_t` below (term lookup stays on the host trie), calls mgpu_execute() and copies
+ * the `mgpu_sqout_t` back into `struct squery_result` (INTEGRATION.md shows the stub).
+ * Plain C, plain pointers and sizes, int status codes (0 = ok); no torch / HIP types.
+ *
+ * Every entry point cites the reference code whose work it takes over
+ * (paths relative to /root/reference/src/main).
+ */
+#ifndef MARLIN_GPU_H
+#define MARLIN_GPU_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGPU_MAX_TERMS   32
+#define MGPU_MAX_WORDS   16
+#define MGPU_MAX_FIELDS  32
+#define MGPU_MAX_AGGS    16
+#define MGPU_MAX_RULES   10
+#define MGPU_MAX_K       1000      /* MAX_HITS_LIMIT, index.h:22 */
+
+enum {
+    MGPU_OK = 0,
+    MGPU_E_HIP = -1,          /* a HIP call failed; see mgpu_last_error() */
+    MGPU_E_ARG = -2,          /* malformed argument */
+    MGPU_E_LIMIT = -3,        /* beyond a documented limit of this implementation */
+    MGPU_E_SCRATCH = -4,      /* position scratch pool exhausted (raise mgpu_ctx_create's pool) */
+    MGPU_E_UNSUPPORTED = -5   /* e.g. R_GEO rule, fast-rank mode */
+};
+
+/* sort.h:7-18 */
+enum { MGPU_R_TYPO, MGPU_R_PROX, MGPU_R_POS, MGPU_R_EXACT, MGPU_R_FIELD, MGPU_R_GEO, MGPU_R_DONE,
+       MGPU_R_COMP, MGPU_R_COMP_ASC, MGPU_R_MAX };
+/* aggs.h:15-23 */
+enum { MGPU_A_ROOT, MGPU_A_MAX, MGPU_A_MIN, MGPU_A_AVG, MGPU_A_STATS, MGPU_A_CARDINALITY };
+
+typedef struct mgpu_shard mgpu_shard_t;   /* HBM mirror of one shard */
+typedef struct mgpu_ctx   mgpu_ctx_t;     /* one execution context = one HIP stream + workspace */
+
+const char *mgpu_last_error(void);
+int mgpu_device_count(void);
+
+/* ---------------------------------------------------------------- mirror ------------------
+ * Source formats: the sets stored by mbmap (mbmap.c:253-283 header + container keys), the
+ * docid2data blob (sindex.c:273-326, 409-496) and num_dbi (sindex.c:528-535).  All arrays are
+ * host memory, copied during the call.  Posting ids ("pid") are chosen by the caller; pid 0 is
+ * reserved for "all used docids" (shard_get_all_docids, shard.c:51-53). */
+typedef struct mgpu_shard_desc {
+    uint32_t max_docid;                 /* docids 1..max_docid */
+    int      num_numbers, num_facets;
+    /* postings, CSR by pid; docids ascending */
+    uint32_t        num_postings;       /* pids 0..num_postings-1 */
+    const uint64_t *post_off;           /* [num_postings + 1] */
+    const uint32_t *post_doc;
+    /* docid2data, raw blobs in the reference layout */
+    const uint64_t *dd_off;             /* [max_docid + 2], blob of doc d = dd[dd_off[d], dd_off[d+1]) */
+    const uint8_t  *dd;
+    /* num_dbi[i] docids in key order (value descending, docid ascending); values stay on the host */
+    uint64_t        np_n[MGPU_MAX_FIELDS];
+    const uint32_t *np_doc[MGPU_MAX_FIELDS];
+} mgpu_shard_desc_t;
+
+/* Builds the mirror on `device`: dense u64 rows for postings with >= 1/32 of the docs, sorted
+ * docid lists for the rest, docword CSR + decoded position pool, per-field facet ordinals and
+ * numeric columns decoded from the blobs.  Takes over mbmap_load_bmap + mdb_get(docid2data). */
+int  mgpu_shard_create(int device, const mgpu_shard_desc_t *desc, mgpu_shard_t **out);
+void mgpu_shard_destroy(mgpu_shard_t *s);
+/* bytes of HBM held by the mirror */
+uint64_t mgpu_shard_bytes(const mgpu_shard_t *s);
+
+/* ---------------------------------------------------------------- plan -------------------- */
+/* filter program: postfix form of the reference's filter tree (filter_apply.c:207-227).
+ * `docs` is the pre-filter docid_map, as in filter_apply's last argument. */
+enum {
+    MGPU_F_PUSH_POSTING,   /* a = pid            (str_eq_filter / bool_eq_filter) */
+    MGPU_F_PUSH_NUMRANGE,  /* a = numeric field, lo..hi = [lo, hi) into np_doc (num_*_filter) */
+    MGPU_F_PUSH_EMPTY,
+    MGPU_F_AND,            /* pop 2, push a & b  (oper_and) */
+    MGPU_F_OR,             /* pop 2, push a | b  (oper_or)  */
+    MGPU_F_DOCS_ANDNOT     /* top = docs & ~top  (ne_filter / nin_filter) */
+};
+typedef struct mgpu_fop { int32_t op; int32_t a; uint64_t lo, hi; } mgpu_fop_t;
+
+/* one entry of the wid table built from all_wordids + per-term wordids + exact wids
+ * (squery.c:48-70, 100-111, 159-166; consumed by docrank.c:84,117,152,256) */
+typedef struct mgpu_wid_entry {
+    uint32_t wid;
+    uint8_t  dist;        /* all_wordids value, 0xFF when absent */
+    uint8_t  mterm;       /* get_matching_term: first term whose wordids holds wid, 0xFF none */
+    uint16_t exact_mask;  /* bit i: wid is the exact wid of query word i */
+} mgpu_wid_entry_t;
+
+typedef struct mgpu_plan {
+    /* terms: termdata[t].tbmap = OR of these postings (process_termresult, squery.c:72-118) */
+    int32_t  num_terms;                         /* 0, 1, 3 or 2n (query.c:489-603) */
+    int32_t  num_words;
+    uint32_t term_npost[MGPU_MAX_TERMS];
+    const uint32_t *term_post[MGPU_MAX_TERMS];  /* pids */
+    uint16_t exact_present;                     /* bit i: exact_docid_map[i] != NULL */
+    /* wid table */
+    uint32_t num_wids;
+    const mgpu_wid_entry_t *wids;
+    /* filter */
+    int32_t  has_filter;
+    int32_t  filter_null;                       /* filter_apply returned NULL -> empty result */
+    int32_t  num_fops;
+    const mgpu_fop_t *fops;
+    /* config (query.h:47-68) */
+    int32_t  hits_per_page, page_num;
+    int32_t  max_facet_results;
+    uint32_t facet_enabled;                     /* bit f */
+    int32_t  rank_by;
+    int32_t  rank_asc;
+    int32_t  rules[MGPU_MAX_RULES];             /* q->rank_rule, MGPU_R_DONE terminated */
+    /* aggs (metric-aggs.h) */
+    int32_t  num_aggs;
+    int32_t  agg_type[MGPU_MAX_AGGS];
+    int32_t  agg_field[MGPU_MAX_AGGS];
+    /* debug captures for parity tests: 1 = docid_map words, 2 = all rank records */
+    int32_t  capture;
+} mgpu_plan_t;
+
+/* ---------------------------------------------------------------- results ----------------- */
+typedef struct mgpu_rank {       /* struct docrank (docrank.h:5-15), same layout */
+    double   compare;
+    uint32_t docid;
+    uint32_t distance;
+    uint16_t position;
+    uint16_t proximity;
+    uint8_t  typos;
+    uint8_t  exact;
+    uint8_t  field;
+    uint8_t  shard_id;
+} mgpu_rank_t;
+
+typedef struct mgpu_facet { uint32_t facet_id; uint32_t count; } mgpu_facet_t;
+
+typedef struct mgpu_agg_out { double sum, min, max; int64_t count; uint32_t card_n; uint32_t *card_ids; } mgpu_agg_out_t;
+
+typedef struct mgpu_sqout {      /* struct squery_result (squery.h:34-46), flat; malloc'd arrays */
+    int32_t   status;
+    uint32_t  num_hits;
+    int32_t   rank_count;
+    mgpu_rank_t *ranks;                          /* sorted by rank rules, ties by docid */
+    int32_t   rcount[MGPU_MAX_FIELDS];           /* fh[f].rcount */
+    mgpu_facet_t *fc[MGPU_MAX_FIELDS];           /* top 2*maxFacetResults by count, ties by facet id */
+    mgpu_agg_out_t aggs[MGPU_MAX_AGGS];
+    uint64_t *dbg_docid_map; uint32_t dbg_words;
+    mgpu_rank_t *dbg_all_ranks;
+} mgpu_sqout_t;
+
+/* ---------------------------------------------------------------- execution --------------- */
+/* scratch_bytes: size of the overflow position pool (0 = default 64 MiB) */
+int  mgpu_ctx_create(int device, uint64_t scratch_bytes, mgpu_ctx_t **out);
+void mgpu_ctx_destroy(mgpu_ctx_t *c);
+
+/* execute_squery (squery.c:459-536) for n (shard, plan) pairs in one batch of launches; all
+ * shards must live on the context's device.  outs[i] is filled (free with mgpu_sqout_free). */
+int  mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_plan_t *plans, int n,
+                  mgpu_sqout_t *outs);
+/* sqresult_free (squery.c:336-356) */
+void mgpu_sqout_free(mgpu_sqout_t *o);
+
+/* device time of the last mgpu_execute on this context, measured with HIP events on the
+ * context's stream: total ms, and per-stage ms (see mgpu_stage_name) */
+#define MGPU_NUM_STAGES 8
+int  mgpu_last_timing(const mgpu_ctx_t *c, float *total_ms, float *stage_ms /* [MGPU_NUM_STAGES] */);
+const char *mgpu_stage_name(int stage);
+/* algorithmic bytes moved by the last mgpu_execute per stage (DESIGN.md byte model) */
+int  mgpu_last_bytes(const mgpu_ctx_t *c, uint64_t *stage_bytes /* [MGPU_NUM_STAGES] */);
+/* enable/disable per-stage event timing (adds event records between kernels) */
+void mgpu_ctx_set_profiling(mgpu_ctx_t *c, int on);
+
+/* ---------------------------------------------------------------- primitives --------------
+ * kernel-level entry points used by the parity tests against bmap.c / cont.c */
+/* bmap_and / oper_or / bmap_andnot / bmap_cardinality on two postings of a mirror; op: 0 and,
+ * 1 or, 2 andnot.  out_words may be NULL; returns the cardinality in *card. */
+int mgpu_posting_op(mgpu_ctx_t *c, mgpu_shard_t *s, int op, uint32_t pid_a, uint32_t pid_b,
+                    uint64_t *out_words, uint32_t nwords, uint64_t *card);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

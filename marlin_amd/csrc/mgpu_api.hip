@@ -1,0 +1,913 @@
+// mgpu_api.hip -- host runtime behind the C ABI of include/marlin_gpu.h.
+//
+// Mirror construction (reference formats -> HBM layouts), per-batch plan lowering, arena
+// layout, launches on one HIP stream, result decode.  No torch, no CPU compute fallback:
+// every documented failure returns an MGPU_E_* code.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "mgpu_types.h"
+
+typedef unsigned long long u64;
+
+extern "C" {
+void mgk_scatter(hipStream_t st, const ScatterItem *items, uint32_t nitems);
+void mgk_formula(hipStream_t st, const SqDev *sqs, const uint32_t *blob, uint32_t max_nblk, uint32_t nsq);
+void mgk_rank(hipStream_t st, const SqDev *sqs, const uint32_t *blob, uint32_t max_n, uint32_t nsq,
+              unsigned long long *pool, uint32_t *pool_used, uint64_t pool_cap);
+void mgk_docproc(hipStream_t st, const SqDev *sqs, uint32_t max_pblocks, uint32_t nsq);
+void mgk_fkeys(hipStream_t st, const void *jobs, uint32_t njobs, uint32_t max_n);
+void mgk_card(hipStream_t st, const void *jobs, uint32_t njobs, uint32_t max_n);
+void mgk_select(hipStream_t st, const SelJob *jobs, const void *outs, uint32_t njobs, uint32_t max_m, int passes);
+void mgk_row_op(hipStream_t st, const unsigned long long *a, const unsigned long long *b, unsigned long long *out,
+                uint32_t W, int op, unsigned long long *card);
+}
+
+struct FkJob { const uint32_t *hist; const uint32_t *ord2id; uint32_t n; uint32_t pad; u64 *key_hi, *key_lo; };
+struct CardJob { const uint32_t *hist; const uint32_t *ord2id; uint32_t n; uint32_t pad; uint32_t *out_ids; uint32_t *out_n; };
+struct SelOut { u64 *out_hi, *out_lo; uint32_t *out_pl; const uint32_t *payload; };
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+    return fail(MGPU_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
+
+extern "C" const char *mgpu_last_error(void) { return g_err.c_str(); }
+extern "C" int mgpu_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+
+// ------------------------------------------------------------------ mirror
+struct mgpu_shard {
+    int device;
+    ShardDev dev;                       // device pointers
+    std::vector<void *> allocs;
+    uint64_t bytes;
+    // host-side facts used when lowering plans
+    std::vector<int32_t> post_dense;    // per pid
+    std::vector<uint64_t> post_off;     // sparse CSR offsets (per pid)
+    uint64_t np_n[MGPU_MAX_FIELDS];
+    double avg_dw;                      // mean docword entries per doc
+    double avg_fv[MGPU_MAX_FIELDS];     // mean facet values per doc
+    uint32_t n_dense;
+};
+
+template <typename T>
+static int upload(mgpu_shard *s, const std::vector<T> &v, const T **out) {
+    size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+    void *p = nullptr;
+    HIPCHK(hipMalloc(&p, bytes));
+    s->allocs.push_back(p);
+    s->bytes += bytes;
+    if (!v.empty()) HIPCHK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = (const T *)p;
+    return MGPU_OK;
+}
+
+static inline const uint8_t *rd_vint(const uint8_t *buf, int *value) {   // read_vint, sindex.c:340-351
+    uint8_t b = *buf++;
+    int i = b & 0x7F;
+    for (int shift = 7; (b & 0x80) != 0; shift += 7) { b = *buf++; i |= (b & 0x7F) << shift; }
+    *value = i;
+    return buf;
+}
+
+extern "C" void mgpu_shard_destroy(mgpu_shard_t *s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    for (void *p : s->allocs) (void)hipFree(p);
+    delete s;
+}
+
+extern "C" uint64_t mgpu_shard_bytes(const mgpu_shard_t *s) { return s ? s->bytes : 0; }
+
+extern "C" int mgpu_shard_create(int device, const mgpu_shard_desc_t *d, mgpu_shard_t **out) {
+    if (!d || !out) return fail(MGPU_E_ARG, "null argument");
+    if (d->num_numbers > MGPU_MAX_FIELDS || d->num_facets > MGPU_MAX_FIELDS)
+        return fail(MGPU_E_LIMIT, "more than 32 numeric or facet fields");
+    HIPCHK(hipSetDevice(device));
+    mgpu_shard *s = new mgpu_shard();
+    s->device = device; s->bytes = 0; s->n_dense = 0;
+    memset(&s->dev, 0, sizeof(s->dev));
+    ShardDev &sd = s->dev;
+    const uint32_t N = d->max_docid + 1;
+    sd.N = N; sd.W = (N + 63) / 64; sd.Wp = (sd.W + 31) & ~31u;
+    sd.num_postings = d->num_postings;
+    sd.num_facets = d->num_facets; sd.num_numbers = d->num_numbers;
+    int rc = MGPU_OK;
+
+    // ---- postings: dense rows for cardinality >= N/32 (a row costs no more than the list), pid 0 always
+    {
+        s->post_dense.assign(d->num_postings, -1);
+        s->post_off.assign((size_t)d->num_postings + 1, 0);
+        std::vector<uint32_t> sparse_doc;
+        std::vector<uint32_t> dense_pids;
+        for (uint32_t p = 0; p < d->num_postings; p++) {
+            uint64_t n = d->post_off[p + 1] - d->post_off[p];
+            bool dense = (p == 0) || (n > 0 && n * 32 >= N);
+            s->post_off[p] = sparse_doc.size();
+            if (dense) { s->post_dense[p] = (int32_t)dense_pids.size(); dense_pids.push_back(p); }
+            else sparse_doc.insert(sparse_doc.end(), d->post_doc + d->post_off[p], d->post_doc + d->post_off[p + 1]);
+        }
+        s->post_off[d->num_postings] = sparse_doc.size();
+        std::vector<u64> rows((size_t)dense_pids.size() * sd.Wp, 0);
+        for (size_t r = 0; r < dense_pids.size(); r++) {
+            uint32_t p = dense_pids[r];
+            u64 *row = rows.data() + r * sd.Wp;
+            for (uint64_t i = d->post_off[p]; i < d->post_off[p + 1]; i++) {
+                uint32_t doc = d->post_doc[i];
+                if (doc >= N) { delete s; return fail(MGPU_E_ARG, "posting docid beyond max_docid"); }
+                row[doc >> 6] |= 1ull << (doc & 63);
+            }
+        }
+        s->n_dense = (uint32_t)dense_pids.size();
+        const u64 *p_rows; const int32_t *p_pd; const u64 *p_off; const uint32_t *p_doc;
+        if ((rc = upload(s, rows, &p_rows)) || (rc = upload(s, s->post_dense, &p_pd)) ||
+            (rc = upload(s, s->post_off, (const uint64_t **)&p_off)) || (rc = upload(s, sparse_doc, &p_doc))) {
+            mgpu_shard_destroy(s); return rc;
+        }
+        sd.dense = (const uint64_t *)p_rows; sd.post_dense = p_pd; sd.post_off = (const uint64_t *)p_off; sd.post_doc = p_doc;
+    }
+
+    // ---- docid2data blobs -> docword CSR + position pool + facet ordinals + numeric columns
+    {
+        std::vector<uint32_t> dw_off(N + 1, 0), pp_off(N + 1, 0);
+        std::vector<uint2> dw;
+        std::vector<uint32_t> pp;
+        std::vector<std::vector<double>> cols(d->num_numbers, std::vector<double>(N, 0.0));
+        std::vector<std::vector<uint32_t>> fa_off(d->num_facets, std::vector<uint32_t>(N + 1, 0));
+        std::vector<std::vector<uint32_t>> fa_ids(d->num_facets);
+        for (uint32_t doc = 1; doc < N; doc++) {
+            dw_off[doc] = (uint32_t)dw.size(); pp_off[doc] = (uint32_t)pp.size();
+            for (int f = 0; f < d->num_facets; f++) fa_off[f][doc] = (uint32_t)fa_ids[f].size();
+            const uint8_t *blob = d->dd + d->dd_off[doc];
+            const uint64_t bsz = d->dd_off[doc + 1] - d->dd_off[doc];
+            if (bsz < 4) continue;
+            uint32_t off; memcpy(&off, blob, 4);
+            for (int i = 0; i < d->num_numbers; i++) memcpy(&cols[i][doc], blob + 4 + (size_t)i * 8, 8);
+            const uint8_t *fpos = blob + 4 + (size_t)d->num_numbers * 8;
+            for (int f = 0; f < d->num_facets; f++) {
+                uint32_t cnt; memcpy(&cnt, fpos, 4);
+                for (uint32_t j = 0; j < cnt; j++) { uint32_t id; memcpy(&id, fpos + 4 + (size_t)j * 4, 4); fa_ids[f].push_back(id); }
+                fpos += 4 + (size_t)cnt * 4;
+            }
+            if ((uint64_t)off + 2 > bsz) continue;
+            const uint8_t *wp = blob + off;
+            uint16_t numwid; memcpy(&numwid, wp, 2);
+            const uint32_t pool_base = (uint32_t)pp.size();
+            for (uint32_t i = 0; i < numwid; i++) {
+                uint32_t wid, info; memcpy(&wid, wp + 2 + (size_t)i * 8, 4); memcpy(&info, wp + 6 + (size_t)i * 8, 4);
+                if (info & 1u) { dw.push_back(make_uint2(wid, info)); continue; }
+                // fill_positions (docrank.c:21-45): freq, then {priority, count, vints, 0xFF} groups
+                const uint8_t *c = wp + (info >> 9);
+                int freq = *c++;
+                const uint32_t start = (uint32_t)pp.size() - pool_base;
+                uint32_t n = 0;
+                while (freq > 0) {
+                    int priority = *c++; int count = *c++;
+                    freq -= count;
+                    while (count > 0) { int position; c = rd_vint(c, &position); pp.push_back(((uint32_t)priority << 16) + (uint32_t)position); n++; count--; }
+                    c++;
+                }
+                if (n > 255 || start >= (1u << 23)) { mgpu_shard_destroy(s); return fail(MGPU_E_LIMIT, "word frequency or document too large for the mirror"); }
+                dw.push_back(make_uint2(wid, (n << 1) | (start << 9)));
+            }
+        }
+        dw_off[N] = (uint32_t)dw.size(); pp_off[N] = (uint32_t)pp.size();
+        dw_off[0] = 0; pp_off[0] = 0;
+        s->avg_dw = N > 1 ? (double)dw.size() / (double)(N - 1) : 0.0;
+        if ((rc = upload(s, dw_off, &sd.dw_off)) || (rc = upload(s, dw, &sd.dw)) ||
+            (rc = upload(s, pp_off, &sd.pp_off)) || (rc = upload(s, pp, &sd.pp))) { mgpu_shard_destroy(s); return rc; }
+        for (int i = 0; i < d->num_numbers; i++)
+            if ((rc = upload(s, cols[i], &sd.num_col[i]))) { mgpu_shard_destroy(s); return rc; }
+        for (int f = 0; f < d->num_facets; f++) {
+            fa_off[f][N] = (uint32_t)fa_ids[f].size(); fa_off[f][0] = 0;
+            std::vector<uint32_t> uniq(fa_ids[f]);
+            std::sort(uniq.begin(), uniq.end());
+            uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+            std::vector<uint32_t> ords(fa_ids[f].size());
+            for (size_t i = 0; i < ords.size(); i++)
+                ords[i] = (uint32_t)(std::lower_bound(uniq.begin(), uniq.end(), fa_ids[f][i]) - uniq.begin());
+            sd.fa_nord[f] = (uint32_t)uniq.size();
+            s->avg_fv[f] = N > 1 ? (double)ords.size() / (double)(N - 1) : 0.0;
+            if ((rc = upload(s, fa_off[f], &sd.fa_off[f])) || (rc = upload(s, ords, &sd.fa_ord[f])) ||
+                (rc = upload(s, uniq, &sd.fa_ord2id[f]))) { mgpu_shard_destroy(s); return rc; }
+        }
+    }
+    // ---- num_dbi docids in key order
+    for (int i = 0; i < d->num_numbers; i++) {
+        s->np_n[i] = d->np_n[i];
+        std::vector<uint32_t> v(d->np_doc[i], d->np_doc[i] + d->np_n[i]);
+        if ((rc = upload(s, v, &sd.np_doc[i]))) { mgpu_shard_destroy(s); return rc; }
+    }
+    *out = s;
+    return MGPU_OK;
+}
+
+// ------------------------------------------------------------------ context
+struct Arena {
+    char *dev = nullptr; size_t cap = 0;
+};
+
+struct mgpu_ctx {
+    int device;
+    hipStream_t stream;
+    Arena arena;
+    char *pin = nullptr; size_t pin_cap = 0;          // pinned staging for uploads
+    char *pin_out = nullptr; size_t pin_out_cap = 0;  // pinned buffer for results
+    u64 *pool = nullptr; uint64_t pool_cap = 0;       // overflow position pool, in u64 entries
+    uint32_t *pool_used = nullptr;
+    hipEvent_t ev[MGPU_NUM_STAGES + 1];
+    int profiling;
+    float stage_ms[MGPU_NUM_STAGES];
+    float total_ms;
+    uint64_t stage_bytes[MGPU_NUM_STAGES];
+};
+
+extern "C" int mgpu_ctx_create(int device, uint64_t scratch_bytes, mgpu_ctx_t **out) {
+    if (!out) return fail(MGPU_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(device));
+    mgpu_ctx *c = new mgpu_ctx();
+    c->device = device; c->profiling = 0; c->total_ms = 0;
+    memset(c->stage_ms, 0, sizeof(c->stage_ms)); memset(c->stage_bytes, 0, sizeof(c->stage_bytes));
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    if (!scratch_bytes) scratch_bytes = 64ull << 20;
+    c->pool_cap = scratch_bytes / 8;
+    HIPCHK(hipMalloc((void **)&c->pool, c->pool_cap * 8));
+    HIPCHK(hipMalloc((void **)&c->pool_used, 256));
+    for (int i = 0; i <= MGPU_NUM_STAGES; i++) HIPCHK(hipEventCreate(&c->ev[i]));
+    *out = c;
+    return MGPU_OK;
+}
+
+extern "C" void mgpu_ctx_destroy(mgpu_ctx_t *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->arena.dev) (void)hipFree(c->arena.dev);
+    if (c->pin) (void)hipHostFree(c->pin);
+    if (c->pin_out) (void)hipHostFree(c->pin_out);
+    (void)hipFree(c->pool); (void)hipFree(c->pool_used);
+    for (int i = 0; i <= MGPU_NUM_STAGES; i++) (void)hipEventDestroy(c->ev[i]);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" void mgpu_ctx_set_profiling(mgpu_ctx_t *c, int on) { if (c) c->profiling = on; }
+
+static const char *k_stage_names[MGPU_NUM_STAGES] = {
+    "upload+clear", "scatter", "formula+compact", "rank", "facets+aggs", "facet-keys", "select", "download" };
+extern "C" const char *mgpu_stage_name(int s) { return (s >= 0 && s < MGPU_NUM_STAGES) ? k_stage_names[s] : ""; }
+
+extern "C" int mgpu_last_timing(const mgpu_ctx_t *c, float *total_ms, float *stage_ms) {
+    if (!c) return MGPU_E_ARG;
+    if (total_ms) *total_ms = c->total_ms;
+    if (stage_ms) memcpy(stage_ms, c->stage_ms, sizeof(c->stage_ms));
+    return MGPU_OK;
+}
+extern "C" int mgpu_last_bytes(const mgpu_ctx_t *c, uint64_t *stage_bytes) {
+    if (!c || !stage_bytes) return MGPU_E_ARG;
+    memcpy(stage_bytes, c->stage_bytes, sizeof(c->stage_bytes));
+    return MGPU_OK;
+}
+
+static int ensure_arena(mgpu_ctx *c, size_t bytes) {
+    if (bytes <= c->arena.cap) return MGPU_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->arena.dev) HIPCHK(hipFree(c->arena.dev));
+    size_t cap = std::max(bytes + bytes / 4, (size_t)(16u << 20));
+    c->arena.dev = nullptr; c->arena.cap = 0;
+    HIPCHK(hipMalloc((void **)&c->arena.dev, cap));
+    c->arena.cap = cap;
+    return MGPU_OK;
+}
+static int ensure_pin(char **p, size_t *cap, size_t bytes) {
+    if (bytes <= *cap) return MGPU_OK;
+    if (*p) HIPCHK(hipHostFree(*p));
+    size_t ncap = std::max(bytes + bytes / 2, (size_t)(1u << 20));
+    *p = nullptr; *cap = 0;
+    HIPCHK(hipHostMalloc((void **)p, ncap, hipHostMallocDefault));
+    *cap = ncap;
+    return MGPU_OK;
+}
+
+struct Bump {
+    size_t off = 0;
+    size_t take(size_t bytes, size_t align = 256) { off = (off + align - 1) / align * align; size_t r = off; off += bytes; return r; }
+};
+
+// result header copied back per squery
+struct ResHdr {
+    uint32_t num_hits, err, ovf_cnt, rank_n;
+    uint32_t fac_n[MGPU_MAX_FIELDS];
+    uint32_t card_n[MGPU_MAX_AGGS];
+    AggPart agg[MGPU_MAX_AGGS];
+};
+
+struct SqHost {                          // host bookkeeping for one squery of the batch
+    size_t hdr_off;                      // into results region
+    uint32_t k;
+    size_t rank_hi, rank_lo, rank_pl;    // results-region offsets
+    int nfac; int fac_field[MGPU_MAX_FIELDS]; uint32_t fac_k[MGPU_MAX_FIELDS];
+    size_t fac_hi[MGPU_MAX_FIELDS], fac_lo[MGPU_MAX_FIELDS], fac_pl[MGPU_MAX_FIELDS];
+    int ncard; int card_agg[MGPU_MAX_AGGS]; size_t card_ids_off[MGPU_MAX_AGGS]; uint32_t card_cap[MGPU_MAX_AGGS];
+    size_t docid_map_off, hits_off, key_hi_off, key_lo_off;
+    int rank_job, fac_job[MGPU_MAX_FIELDS];
+    KeyField kf[8]; int nkf;
+    uint64_t formula_rows;               // rows read by the formula kernel
+    uint64_t scatter_docs;
+};
+
+static int build_key_layout(const mgpu_plan_t &p, KeyField *kf, int *nkf) {
+    int n = 0, acc = 0;
+    bool seen[8] = {false, false, false, false, false, false, false, false};
+    auto add = [&](int kind, int bits) {
+        if (seen[kind]) return;
+        seen[kind] = true;
+        kf[n].kind = (int8_t)kind; kf[n].bits = (uint8_t)bits; acc += bits; kf[n].shift = (uint8_t)(128 - acc); kf[n].hi = 0; n++;
+    };
+    for (int i = 0; i < MGPU_MAX_RULES; i++) {
+        int r = p.rules[i];
+        if (r == MGPU_R_DONE || r == MGPU_R_MAX) break;
+        switch (r) {
+            case MGPU_R_TYPO: add(KF_TYPO, 8); break;
+            case MGPU_R_PROX: add(KF_PROX, 16); break;
+            case MGPU_R_POS: add(KF_POS, 16); break;
+            case MGPU_R_EXACT: add(KF_EXACT, 8); break;
+            case MGPU_R_FIELD: add(KF_FIELD, 8); break;
+            case MGPU_R_COMP: case MGPU_R_COMP_ASC:
+                if (p.rank_by < 0) return fail(MGPU_E_ARG, "compare rule without rank_by");
+                if (!seen[KF_COMP_DESC] && !seen[KF_COMP_ASC]) add(r == MGPU_R_COMP ? KF_COMP_DESC : KF_COMP_ASC, 64);
+                break;
+            default: return fail(MGPU_E_UNSUPPORTED, "rank rule not supported (geo)");
+        }
+    }
+    // fields outside the rule list ride in the low bits so the record can be rebuilt; they only
+    // order documents the reference's comparator calls equal
+    add(KF_TYPO, 8); add(KF_PROX, 16); add(KF_POS, 16); add(KF_EXACT, 8); add(KF_FIELD, 8);
+    if (acc > 128) return fail(MGPU_E_LIMIT, "rank key wider than 128 bits");
+    *nkf = n;
+    return MGPU_OK;
+}
+
+static void decode_key(const KeyField *kf, int nkf, u64 hi, u64 lo, mgpu_rank_t *r) {
+    unsigned __int128 key = ((unsigned __int128)hi << 64) | lo;
+    r->compare = 0.0;
+    for (int i = 0; i < nkf; i++) {
+        u64 v = (u64)(key >> kf[i].shift);
+        if (kf[i].bits < 64) v &= ((1ull << kf[i].bits) - 1);
+        switch (kf[i].kind) {
+            case KF_TYPO: r->typos = (uint8_t)v; break;
+            case KF_PROX: r->proximity = (uint16_t)v; break;
+            case KF_POS: r->position = (uint16_t)v; break;
+            case KF_EXACT: r->exact = (uint8_t)(255 - v); break;
+            case KF_FIELD: r->field = (uint8_t)v; break;
+            case KF_COMP_DESC: v = ~v; /* fallthrough */
+            case KF_COMP_ASC: {
+                u64 bits = (v & 0x8000000000000000ull) ? (v ^ 0x8000000000000000ull) : ~v;
+                memcpy(&r->compare, &bits, 8);
+            } break;
+        }
+    }
+}
+
+extern "C" void mgpu_sqout_free(mgpu_sqout_t *o) {
+    if (!o) return;
+    free(o->ranks);
+    for (int f = 0; f < MGPU_MAX_FIELDS; f++) free(o->fc[f]);
+    for (int a = 0; a < MGPU_MAX_AGGS; a++) free(o->aggs[a].card_ids);
+    free(o->dbg_docid_map); free(o->dbg_all_ranks);
+    memset(o, 0, sizeof(*o));
+}
+
+extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_plan_t *plans, int n,
+                            mgpu_sqout_t *outs) {
+    if (!c || !shards || !plans || !outs || n <= 0) return fail(MGPU_E_ARG, "bad argument");
+    if (n > 65535) return fail(MGPU_E_LIMIT, "batch larger than 65535");
+    HIPCHK(hipSetDevice(c->device));
+    for (int i = 0; i < n; i++) memset(&outs[i], 0, sizeof(outs[i]));
+
+    // ---------------- lower plans into host staging ----------------
+    std::vector<SqDev> sqd(n);
+    std::vector<SqHost> sqh(n);
+    std::vector<uint32_t> blob;
+    struct PendingScatter { int sq; int row; const uint32_t *src_dev; uint64_t n; };
+    std::vector<PendingScatter> pscat;
+    std::vector<SelJob> seljobs; std::vector<SelOut> selouts;
+    std::vector<FkJob> fkjobs; std::vector<CardJob> cardjobs;
+    struct JobFix { int sq; int kind; int field; };       // kind 0 rank, 1 facet
+    std::vector<JobFix> jobfix;
+
+    Bump res;          // results region (inside the zero region, first)
+    Bump zer;          // rest of the zero region
+    Bump nz;           // non-zero region
+    std::vector<int> nrows(n, 0);
+    uint32_t max_nblk = 1, max_N = 1, max_pblocks = 1, max_fk = 1, max_selm = 1;
+
+    struct Offs {      // arena offsets per squery (zero or nonzero region relative)
+        size_t rows, hist[MGPU_MAX_FIELDS], andor, ovfcnt, docmap, blk, hits, khi, klo, ovfl, aggpart;
+        size_t fkhi[MGPU_MAX_FIELDS], fklo[MGPU_MAX_FIELDS];
+    };
+    std::vector<Offs> offs(n);
+    struct SelOff { size_t cand0, cand1, hist, ctl, outidx; uint32_t mcap; };
+    std::vector<SelOff> seloff;
+
+    for (int i = 0; i < n; i++) {
+        const mgpu_plan_t &p = plans[i];
+        mgpu_shard *sh = shards[i];
+        if (!sh || sh->device != c->device) return fail(MGPU_E_ARG, "shard not on the context's device");
+        if (p.num_terms < 0 || p.num_terms > MGPU_MAX_TERMS || p.num_words > MGPU_MAX_WORDS)
+            return fail(MGPU_E_LIMIT, "too many query terms or words");
+        if (p.num_terms == 2 || (p.num_terms > 3 && (p.num_terms & 1))) return fail(MGPU_E_ARG, "num_terms must be 0, 1, 3 or even");
+        SqDev &q = sqd[i]; SqHost &h = sqh[i];
+        memset(&q, 0, sizeof(q)); memset(&h, 0, sizeof(h));
+        q.sh = sh->dev;
+        const ShardDev &sd = sh->dev;
+        q.num_words = p.num_words;
+        q.empty = (p.has_filter && p.filter_null) ? 1 : 0;
+        q.nblk = (sd.W + MG_WORDS_PER_BLOCK - 1) / MG_WORDS_PER_BLOCK;
+        max_nblk = std::max(max_nblk, q.nblk); max_N = std::max(max_N, sd.N);
+        h.formula_rows = 1; h.scatter_docs = 0;
+
+        auto use_posting = [&](uint32_t pid, int *row_io, std::vector<uint32_t> *dense_list) -> int {
+            // returns 0 and either appends a dense row index or schedules a scatter into *row_io
+            if (pid >= sd.num_postings) return fail(MGPU_E_ARG, "posting id out of range");
+            int32_t di = sh->post_dense[pid];
+            if (di >= 0) { dense_list->push_back((uint32_t)di); return MGPU_OK; }
+            uint64_t cnt = sh->post_off[pid + 1] - sh->post_off[pid];
+            if (!cnt) return MGPU_OK;
+            if (*row_io < 0) *row_io = nrows[i]++;
+            pscat.push_back({i, *row_io, sd.post_doc + sh->post_off[pid], cnt});
+            h.scatter_docs += cnt;
+            return MGPU_OK;
+        };
+
+        // terms (num_terms == 0 -> every used docid, shard.c:51-53)
+        int nt = p.num_terms;
+        if (nt == 0) {
+            q.num_terms = 1;
+            q.term_dense_off[0] = (uint32_t)blob.size();
+            blob.push_back((uint32_t)sh->post_dense[0]);
+            q.term_dense_off[1] = (uint32_t)blob.size();
+            q.term_row[0] = -1;
+            h.formula_rows += 1;
+        } else {
+            q.num_terms = nt;
+            for (int t = 0; t < nt; t++) {
+                std::vector<uint32_t> dl;
+                int row = -1;
+                for (uint32_t j = 0; j < p.term_npost[t]; j++) {
+                    int rc = use_posting(p.term_post[t][j], &row, &dl);
+                    if (rc) return rc;
+                }
+                std::sort(dl.begin(), dl.end());
+                dl.erase(std::unique(dl.begin(), dl.end()), dl.end());
+                q.term_dense_off[t] = (uint32_t)blob.size();
+                blob.insert(blob.end(), dl.begin(), dl.end());
+                q.term_dense_off[t + 1] = (uint32_t)blob.size();
+                q.term_row[t] = row;
+                h.formula_rows += dl.size() + (row >= 0 ? 1 : 0);
+            }
+        }
+        // filter program
+        if (p.has_filter && !p.filter_null) {
+            int depth = 0;
+            q.fops_off = (uint32_t)blob.size();
+            q.num_fops = p.num_fops;
+            std::vector<uint32_t> fo;
+            for (int j = 0; j < p.num_fops; j++) {
+                const mgpu_fop_t &op = p.fops[j];
+                int a = 0;
+                switch (op.op) {
+                    case MGPU_F_PUSH_POSTING: {
+                        std::vector<uint32_t> dl; int row = -1;
+                        int rc = use_posting((uint32_t)op.a, &row, &dl);
+                        if (rc) return rc;
+                        if (!dl.empty()) a = (int)dl[0];
+                        else if (row >= 0) a = ~row;
+                        else { fo.push_back(MGPU_F_PUSH_EMPTY); fo.push_back(0); depth++; continue; }
+                        depth++; h.formula_rows++;
+                    } break;
+                    case MGPU_F_PUSH_NUMRANGE: {
+                        if (op.a < 0 || op.a >= sd.num_numbers || op.hi > sh->np_n[op.a] || op.lo > op.hi)
+                            return fail(MGPU_E_ARG, "numeric range out of bounds");
+                        if (op.hi == op.lo) { fo.push_back(MGPU_F_PUSH_EMPTY); fo.push_back(0); depth++; continue; }
+                        int row = nrows[i]++;
+                        pscat.push_back({i, row, sd.np_doc[op.a] + op.lo, op.hi - op.lo});
+                        h.scatter_docs += op.hi - op.lo;
+                        a = ~row; depth++; h.formula_rows++;
+                    } break;
+                    case MGPU_F_PUSH_EMPTY: depth++; break;
+                    case MGPU_F_AND: case MGPU_F_OR: if (depth < 2) return fail(MGPU_E_ARG, "filter program underflow"); depth--; break;
+                    case MGPU_F_DOCS_ANDNOT: if (depth < 1) return fail(MGPU_E_ARG, "filter program underflow"); break;
+                    default: return fail(MGPU_E_ARG, "bad filter op");
+                }
+                if (depth > MG_MAX_STACK) return fail(MGPU_E_LIMIT, "filter nesting deeper than 8");
+                fo.push_back((uint32_t)op.op); fo.push_back((uint32_t)a);
+            }
+            if (depth != 1) return fail(MGPU_E_ARG, "filter program must leave one value");
+            q.num_fops = (int)(fo.size() / 2);
+            blob.insert(blob.end(), fo.begin(), fo.end());
+        }
+        // wid table
+        {
+            uint32_t cap = 2; while (cap < 2 * p.num_wids + 2) cap <<= 1;
+            q.hash_off = (uint32_t)blob.size(); q.hash_mask = cap - 1;
+            size_t base = blob.size();
+            blob.resize(base + (size_t)cap * 2, 0);
+            for (uint32_t j = 0; j < p.num_wids; j++) {
+                const mgpu_wid_entry_t &e = p.wids[j];
+                if (e.wid == 0) return fail(MGPU_E_ARG, "wid 0 in wid table");
+                uint32_t hsh = e.wid; hsh ^= hsh >> 16; hsh *= 0x7feb352dU; hsh ^= hsh >> 15; hsh *= 0x846ca68bU; hsh ^= hsh >> 16;
+                uint32_t slot = hsh & (cap - 1);
+                while (blob[base + slot * 2] != 0 && blob[base + slot * 2] != e.wid) slot = (slot + 1) & (cap - 1);
+                blob[base + slot * 2] = e.wid;
+                blob[base + slot * 2 + 1] = (uint32_t)e.dist | ((uint32_t)e.mterm << 8) | ((uint32_t)e.exact_mask << 16);
+            }
+        }
+        q.exact_present = p.exact_present;
+        q.do_rank = (p.hits_per_page > 0 && p.num_words > 0) ? 1 : 0;
+        q.rank_by = p.rank_by;
+        if (p.rank_by >= sd.num_numbers) return fail(MGPU_E_ARG, "rank_by field out of range");
+        int rc = build_key_layout(p, h.kf, &h.nkf);
+        if (rc) return rc;
+        q.nkf = h.nkf; memcpy(q.kf, h.kf, sizeof(h.kf));
+        long kk = (long)p.hits_per_page * (long)p.page_num;
+        if (kk < 0) kk = 0;
+        if (kk > MG_SEL_FINAL) return fail(MGPU_E_LIMIT, "hitsPerPage * page above 2048");
+        h.k = (uint32_t)kk;
+
+        // histograms: enabled facets (when maxFacetResults > 0) and cardinality-agg fields
+        uint32_t hmask = 0;
+        if (p.max_facet_results > 0) hmask |= p.facet_enabled;
+        q.num_aggs = p.num_aggs;
+        if (p.num_aggs > MGPU_MAX_AGGS) return fail(MGPU_E_LIMIT, "too many aggregations");
+        for (int a = 0; a < p.num_aggs; a++) {
+            q.agg_type[a] = p.agg_type[a]; q.agg_field[a] = p.agg_field[a];
+            if (p.agg_type[a] == MGPU_A_CARDINALITY) {
+                if (p.agg_field[a] < 0 || p.agg_field[a] >= sd.num_facets) return fail(MGPU_E_ARG, "cardinality field out of range");
+                hmask |= 1u << p.agg_field[a];
+            } else if (p.agg_field[a] < 0 || p.agg_field[a] >= sd.num_numbers) return fail(MGPU_E_ARG, "agg field out of range");
+        }
+        if (sd.num_facets < 32) hmask &= (1u << sd.num_facets) - 1;
+        q.hist_mask = hmask;
+        q.nproc_blocks = std::min<uint32_t>(512, std::max<uint32_t>(1, (sd.N + 1023) / 1024));
+        max_pblocks = std::max(max_pblocks, q.nproc_blocks);
+
+        // ---- arena layout for this squery
+        Offs &o = offs[i];
+        h.hdr_off = res.take(sizeof(ResHdr));
+        if (h.k) {
+            h.rank_hi = res.take((size_t)h.k * 8); h.rank_lo = res.take((size_t)h.k * 8); h.rank_pl = res.take((size_t)h.k * 4);
+        }
+        h.nfac = 0;
+        if (p.max_facet_results > 0) {
+            for (int f = 0; f < sd.num_facets; f++) {
+                if (!((p.facet_enabled >> f) & 1u) || sd.fa_nord[f] == 0) continue;
+                uint32_t fk = std::min<uint32_t>((uint32_t)p.max_facet_results * 2u, sd.fa_nord[f]);
+                if (fk > MG_SEL_FINAL) return fail(MGPU_E_LIMIT, "2*maxFacetResults (capped by distinct values) above 2048");
+                int j = h.nfac++;
+                h.fac_field[j] = f; h.fac_k[j] = fk;
+                h.fac_hi[j] = res.take((size_t)fk * 8); h.fac_lo[j] = res.take((size_t)fk * 8); h.fac_pl[j] = res.take((size_t)fk * 4);
+            }
+        }
+        o.rows = 0;   // filled after nrows is final (below)
+        for (int f = 0; f < sd.num_facets; f++) if ((hmask >> f) & 1u) o.hist[f] = zer.take((size_t)sd.fa_nord[f] * 4 + 4);
+        o.andor = zer.take(32); o.ovfcnt = zer.take(4);
+        o.docmap = nz.take((size_t)sd.Wp * 8); o.blk = nz.take((size_t)(q.nblk + 1) * 4);
+        o.hits = nz.take((size_t)sd.N * 4);
+        o.khi = nz.take((size_t)sd.N * 8); o.klo = nz.take((size_t)sd.N * 8);
+        o.ovfl = nz.take((size_t)sd.N * 4);
+        o.aggpart = nz.take((size_t)q.nproc_blocks * std::max(1, p.num_aggs) * sizeof(AggPart));
+        for (int j = 0; j < h.nfac; j++) {
+            int f = h.fac_field[j];
+            o.fkhi[f] = nz.take((size_t)sd.fa_nord[f] * 8); o.fklo[f] = nz.take((size_t)sd.fa_nord[f] * 8);
+            max_fk = std::max(max_fk, sd.fa_nord[f]);
+        }
+        h.ncard = 0;
+        for (int a = 0; a < p.num_aggs; a++) {
+            if (p.agg_type[a] != MGPU_A_CARDINALITY) continue;
+            int j = h.ncard++;
+            h.card_agg[j] = a; h.card_cap[j] = sd.fa_nord[p.agg_field[a]];
+            h.card_ids_off[j] = nz.take((size_t)h.card_cap[j] * 4 + 4);
+            max_fk = std::max(max_fk, sd.fa_nord[p.agg_field[a]]);
+        }
+        // selection jobs
+        h.rank_job = -1;
+        if (h.k) {
+            h.rank_job = (int)seloff.size();
+            SelOff so; so.mcap = sd.N;
+            so.cand0 = nz.take((size_t)sd.N * 4); so.cand1 = nz.take((size_t)sd.N * 4);
+            so.hist = zer.take(MG_SEL_BINS * 4); so.ctl = zer.take(SEL_WORDS * 4); so.outidx = nz.take((size_t)MG_SEL_FINAL * 4);
+            seloff.push_back(so); jobfix.push_back({i, 0, 0});
+            max_selm = std::max(max_selm, sd.N);
+        }
+        for (int j = 0; j < h.nfac; j++) {
+            int f = h.fac_field[j];
+            h.fac_job[j] = (int)seloff.size();
+            SelOff so; so.mcap = sd.fa_nord[f];
+            so.cand0 = nz.take((size_t)so.mcap * 4); so.cand1 = nz.take((size_t)so.mcap * 4);
+            so.hist = zer.take(MG_SEL_BINS * 4); so.ctl = zer.take(SEL_WORDS * 4); so.outidx = nz.take((size_t)MG_SEL_FINAL * 4);
+            seloff.push_back(so); jobfix.push_back({i, 1, j});
+            max_selm = std::max(max_selm, so.mcap);
+        }
+    }
+    // scratch rows (zero region), now that row counts are known
+    for (int i = 0; i < n; i++) offs[i].rows = zer.take((size_t)std::max(nrows[i], 1) * sqd[i].sh.Wp * 8);
+
+    // scatter work items
+    std::vector<ScatterItem> items;
+    // region bases
+    const size_t res_bytes = (res.off + 255) / 256 * 256;
+    const size_t zero_bytes = res_bytes + ((zer.off + 255) / 256 * 256);
+    const size_t nz_base = zero_bytes;
+    const size_t nz_bytes = (nz.off + 255) / 256 * 256;
+    // upload region layout
+    Bump up;
+    const size_t up_sq = up.take(sizeof(SqDev) * n);
+    const size_t up_blob = up.take(std::max<size_t>(blob.size(), 1) * 4);
+    size_t nitems = 0;
+    for (auto &ps : pscat) nitems += (ps.n + MG_SCATTER_CHUNK - 1) / MG_SCATTER_CHUNK;
+    const size_t up_items = up.take(std::max<size_t>(nitems, 1) * sizeof(ScatterItem));
+    const size_t up_sel = up.take(std::max<size_t>(seloff.size(), 1) * sizeof(SelJob));
+    const size_t up_selout = up.take(std::max<size_t>(seloff.size(), 1) * sizeof(SelOut));
+    size_t nfk = 0, ncard = 0;
+    for (int i = 0; i < n; i++) { nfk += sqh[i].nfac; ncard += sqh[i].ncard; }
+    const size_t up_fk = up.take(std::max<size_t>(nfk, 1) * sizeof(FkJob));
+    const size_t up_card = up.take(std::max<size_t>(ncard, 1) * sizeof(CardJob));
+    const size_t up_bytes = (up.off + 255) / 256 * 256;
+    const size_t up_base = nz_base + nz_bytes;
+    const size_t total = up_base + up_bytes;
+
+    int rc = ensure_arena(c, total);
+    if (rc) return rc;
+    if ((rc = ensure_pin(&c->pin, &c->pin_cap, up_bytes))) return rc;
+    if ((rc = ensure_pin(&c->pin_out, &c->pin_out_cap, res_bytes))) return rc;
+    char *A = c->arena.dev;
+    char *R = A;                       // results region
+    char *Z = A + res_bytes;           // remaining zero region
+    char *NZ = A + nz_base;
+    char *UP = A + up_base;
+
+    // fix up device pointers
+    for (int i = 0; i < n; i++) {
+        SqDev &q = sqd[i]; SqHost &h = sqh[i]; Offs &o = offs[i];
+        ResHdr *hdr = (ResHdr *)(R + h.hdr_off);
+        q.rows = (uint64_t *)(Z + o.rows);
+        q.docid_map = (uint64_t *)(NZ + o.docmap);
+        q.blk_cnt = (uint32_t *)(NZ + o.blk);
+        q.num_hits = &hdr->num_hits; q.err = &hdr->err; q.ovf_cnt = (uint32_t *)(Z + o.ovfcnt);
+        q.hits = (uint32_t *)(NZ + o.hits);
+        q.key_hi = (uint64_t *)(NZ + o.khi); q.key_lo = (uint64_t *)(NZ + o.klo);
+        q.key_andor = (uint64_t *)(Z + o.andor);
+        q.ovf_list = (uint32_t *)(NZ + o.ovfl);
+        for (int f = 0; f < q.sh.num_facets; f++) if ((q.hist_mask >> f) & 1u) q.hist[f] = (uint32_t *)(Z + o.hist[f]);
+        q.agg_part = (AggPart *)(NZ + o.aggpart);
+        q.agg_out = hdr->agg;
+        h.docid_map_off = nz_base + o.docmap; h.hits_off = nz_base + o.hits;
+        h.key_hi_off = nz_base + o.khi; h.key_lo_off = nz_base + o.klo;
+    }
+    for (auto &ps : pscat) {
+        SqDev &q = sqd[ps.sq];
+        uint64_t *dst = q.rows + (size_t)ps.row * q.sh.Wp;
+        for (uint64_t at = 0; at < ps.n; at += MG_SCATTER_CHUNK) {
+            ScatterItem it; it.src = ps.src_dev + at; it.dst = dst;
+            it.n = (uint32_t)std::min<uint64_t>(MG_SCATTER_CHUNK, ps.n - at); it.pad = 0;
+            items.push_back(it);
+        }
+    }
+    seljobs.resize(seloff.size()); selouts.resize(seloff.size());
+    for (size_t j = 0; j < seloff.size(); j++) {
+        const SelOff &so = seloff[j]; const JobFix &jf = jobfix[j];
+        SqDev &q = sqd[jf.sq]; SqHost &h = sqh[jf.sq];
+        ResHdr *hdr = (ResHdr *)(R + h.hdr_off);
+        SelJob &sj = seljobs[j]; SelOut &so2 = selouts[j];
+        memset(&sj, 0, sizeof(sj));
+        sj.cand[0] = (uint32_t *)(NZ + so.cand0); sj.cand[1] = (uint32_t *)(NZ + so.cand1);
+        sj.hist = (uint32_t *)(Z + so.hist); sj.ctl = (uint32_t *)(Z + so.ctl);
+        sj.out_idx = (uint32_t *)(NZ + so.outidx); sj.m_cap = so.mcap;
+        if (jf.kind == 0) {
+            sj.key_hi = q.key_hi; sj.key_lo = q.key_lo; sj.m_ptr = q.num_hits; sj.k = h.k;
+            sj.out_n = &hdr->rank_n; sj.mask = q.key_andor; sj.skip_ones = 0;
+            so2.out_hi = (u64 *)(R + h.rank_hi); so2.out_lo = (u64 *)(R + h.rank_lo);
+            so2.out_pl = (uint32_t *)(R + h.rank_pl); so2.payload = q.hits;
+        } else {
+            int f = h.fac_field[jf.field];
+            Offs &o = offs[jf.sq];
+            q.fkey_hi[f] = (uint64_t *)(NZ + o.fkhi[f]); q.fkey_lo[f] = (uint64_t *)(NZ + o.fklo[f]);
+            sj.key_hi = q.fkey_hi[f]; sj.key_lo = q.fkey_lo[f];
+            sj.m_ptr = &q.sh.fa_nord[f];   // patched below to a device address
+            sj.k = h.fac_k[jf.field]; sj.out_n = &hdr->fac_n[jf.field]; sj.mask = nullptr; sj.skip_ones = 1;
+            so2.out_hi = (u64 *)(R + h.fac_hi[jf.field]); so2.out_lo = (u64 *)(R + h.fac_lo[jf.field]);
+            so2.out_pl = (uint32_t *)(R + h.fac_pl[jf.field]); so2.payload = nullptr;
+            // the bin count lives in the uploaded SqDev copy
+            const SqDev *dq = (const SqDev *)(UP + up_sq) + jf.sq;
+            sj.m_ptr = &dq->sh.fa_nord[f];
+            FkJob fj; fj.hist = q.hist[f]; fj.ord2id = q.sh.fa_ord2id[f]; fj.n = q.sh.fa_nord[f]; fj.pad = 0;
+            fj.key_hi = (u64 *)q.fkey_hi[f]; fj.key_lo = (u64 *)q.fkey_lo[f];
+            fkjobs.push_back(fj);
+        }
+    }
+    for (int i = 0; i < n; i++) {
+        SqHost &h = sqh[i]; SqDev &q = sqd[i];
+        ResHdr *hdr = (ResHdr *)(R + h.hdr_off);
+        for (int j = 0; j < h.ncard; j++) {
+            int f = q.agg_field[h.card_agg[j]];
+            CardJob cj; cj.hist = q.hist[f]; cj.ord2id = q.sh.fa_ord2id[f]; cj.n = q.sh.fa_nord[f]; cj.pad = 0;
+            cj.out_ids = (uint32_t *)(A + nz_base + h.card_ids_off[j]); cj.out_n = &hdr->card_n[j];
+            cardjobs.push_back(cj);
+        }
+    }
+    // need_keys: the rank kernel has nothing to do when no hits are requested
+    for (int i = 0; i < n; i++) if (!sqh[i].k) sqd[i].do_rank = -1;
+
+    // staging copy
+    memcpy(c->pin + up_sq, sqd.data(), sizeof(SqDev) * n);
+    if (!blob.empty()) memcpy(c->pin + up_blob, blob.data(), blob.size() * 4);
+    if (!items.empty()) memcpy(c->pin + up_items, items.data(), items.size() * sizeof(ScatterItem));
+    if (!seljobs.empty()) { memcpy(c->pin + up_sel, seljobs.data(), seljobs.size() * sizeof(SelJob));
+                            memcpy(c->pin + up_selout, selouts.data(), selouts.size() * sizeof(SelOut)); }
+    if (!fkjobs.empty()) memcpy(c->pin + up_fk, fkjobs.data(), fkjobs.size() * sizeof(FkJob));
+    if (!cardjobs.empty()) memcpy(c->pin + up_card, cardjobs.data(), cardjobs.size() * sizeof(CardJob));
+
+    // ---------------- launches ----------------
+    hipStream_t st = c->stream;
+    const SqDev *d_sq = (const SqDev *)(UP + up_sq);
+    const uint32_t *d_blob = (const uint32_t *)(UP + up_blob);
+    const bool prof = c->profiling != 0;
+    int evi = 0;
+    auto mark = [&]() { if (prof) (void)hipEventRecord(c->ev[evi++], st); };
+    (void)hipEventRecord(c->ev[0], st); evi = 1;
+    HIPCHK(hipMemsetAsync(A, 0, zero_bytes, st));
+    HIPCHK(hipMemsetAsync(c->pool_used, 0, 4, st));
+    HIPCHK(hipMemcpyAsync(UP, c->pin, up_bytes, hipMemcpyHostToDevice, st));
+    mark();
+    mgk_scatter(st, (const ScatterItem *)(UP + up_items), (uint32_t)items.size());
+    mark();
+    mgk_formula(st, d_sq, d_blob, max_nblk, (uint32_t)n);
+    mark();
+    mgk_rank(st, d_sq, d_blob, max_N, (uint32_t)n, c->pool, c->pool_used, c->pool_cap);
+    mark();
+    mgk_docproc(st, d_sq, max_pblocks, (uint32_t)n);
+    mark();
+    mgk_fkeys(st, UP + up_fk, (uint32_t)fkjobs.size(), max_fk);
+    mgk_card(st, UP + up_card, (uint32_t)cardjobs.size(), max_fk);
+    mark();
+    mgk_select(st, (const SelJob *)(UP + up_sel), UP + up_selout, (uint32_t)seljobs.size(), max_selm, MG_SEL_PASSES);
+    mark();
+    HIPCHK(hipMemcpyAsync(c->pin_out, R, res_bytes, hipMemcpyDeviceToHost, st));
+    if (prof) { (void)hipEventRecord(c->ev[evi++], st); } else { (void)hipEventRecord(c->ev[1], st); }
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+
+    // a selection that needed more than MG_SEL_PASSES passes: run further rounds
+    for (int round = 0; round < 8; round++) {
+        bool again = false;
+        for (size_t j = 0; j < seloff.size() && !again; j++) {
+            const JobFix &jf = jobfix[j]; SqHost &h = sqh[jf.sq];
+            ResHdr *hdr = (ResHdr *)(c->pin_out + h.hdr_off);
+            uint32_t on = jf.kind == 0 ? hdr->rank_n : hdr->fac_n[jf.field];
+            if (on == 0xFFFFFFFFu) again = true;
+        }
+        if (!again) break;
+        mgk_select(st, (const SelJob *)(UP + up_sel), UP + up_selout, (uint32_t)seljobs.size(), max_selm, MG_SEL_PASSES);
+        HIPCHK(hipMemcpyAsync(c->pin_out, R, res_bytes, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+
+    if (prof) {
+        float tot = 0;
+        for (int sidx = 0; sidx < MGPU_NUM_STAGES; sidx++) {
+            float ms = 0; (void)hipEventElapsedTime(&ms, c->ev[sidx], c->ev[sidx + 1]);
+            c->stage_ms[sidx] = ms; tot += ms;
+        }
+        c->total_ms = tot;
+    } else {
+        float ms = 0; (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
+        c->total_ms = ms;
+    }
+
+    // ---------------- decode ----------------
+    memset(c->stage_bytes, 0, sizeof(c->stage_bytes));
+    int worst = MGPU_OK;
+    for (int i = 0; i < n; i++) {
+        const mgpu_plan_t &p = plans[i];
+        SqHost &h = sqh[i]; SqDev &q = sqd[i]; mgpu_shard *sh = shards[i];
+        mgpu_sqout_t &o = outs[i];
+        const ResHdr *hdr = (const ResHdr *)(c->pin_out + h.hdr_off);
+        o.num_hits = hdr->num_hits;
+        if (hdr->err) { o.status = -(int)hdr->err; worst = o.status; g_err = "device reported an error (position scratch pool exhausted)"; continue; }
+        const uint64_t M = hdr->num_hits;
+        // ranks
+        uint32_t rn = h.k ? hdr->rank_n : 0;
+        if (rn == 0xFFFFFFFFu) { o.status = MGPU_E_LIMIT; worst = o.status; g_err = "selection did not converge"; continue; }
+        o.rank_count = (int)rn;
+        o.ranks = (mgpu_rank_t *)calloc(std::max<uint32_t>(rn, 1), sizeof(mgpu_rank_t));
+        const u64 *rhi = (const u64 *)(c->pin_out + h.rank_hi), *rlo = (const u64 *)(c->pin_out + h.rank_lo);
+        const uint32_t *rpl = (const uint32_t *)(c->pin_out + h.rank_pl);
+        for (uint32_t j = 0; j < rn; j++) { decode_key(h.kf, h.nkf, rhi[j], rlo[j], &o.ranks[j]); o.ranks[j].docid = rpl[j]; }
+        // facets
+        for (int j = 0; j < h.nfac; j++) {
+            int f = h.fac_field[j];
+            uint32_t fn = hdr->fac_n[j];
+            if (fn == 0xFFFFFFFFu) { o.status = MGPU_E_LIMIT; worst = o.status; g_err = "facet selection did not converge"; fn = 0; }
+            o.rcount[f] = (int)fn;
+            o.fc[f] = (mgpu_facet_t *)calloc(std::max<uint32_t>(fn, 1), sizeof(mgpu_facet_t));
+            const u64 *fhi = (const u64 *)(c->pin_out + h.fac_hi[j]), *flo = (const u64 *)(c->pin_out + h.fac_lo[j]);
+            for (uint32_t x = 0; x < fn; x++) { o.fc[f][x].facet_id = (uint32_t)flo[x]; o.fc[f][x].count = 0xFFFFFFFFu - (uint32_t)fhi[x]; }
+        }
+        // aggs
+        for (int a = 0; a < p.num_aggs; a++) {
+            o.aggs[a].sum = hdr->agg[a].sum; o.aggs[a].min = hdr->agg[a].mn; o.aggs[a].max = hdr->agg[a].mx;
+            o.aggs[a].count = (int64_t)hdr->agg[a].cnt;
+        }
+        for (int j = 0; j < h.ncard; j++) {
+            int a = h.card_agg[j];
+            uint32_t cn = hdr->card_n[j];
+            o.aggs[a].card_n = cn;
+            o.aggs[a].card_ids = (uint32_t *)malloc(std::max<uint32_t>(cn, 1) * 4);
+            if (cn) HIPCHK(hipMemcpy(o.aggs[a].card_ids, A + nz_base + h.card_ids_off[j], (size_t)cn * 4, hipMemcpyDeviceToHost));
+            std::sort(o.aggs[a].card_ids, o.aggs[a].card_ids + cn);
+        }
+        // debug captures
+        if (p.capture & 1) {
+            o.dbg_words = q.sh.W;
+            o.dbg_docid_map = (uint64_t *)malloc(std::max<size_t>(q.sh.W, 1) * 8);
+            HIPCHK(hipMemcpy(o.dbg_docid_map, A + h.docid_map_off, (size_t)q.sh.W * 8, hipMemcpyDeviceToHost));
+        }
+        if ((p.capture & 2) && h.k) {
+            std::vector<u64> khi(M), klo(M); std::vector<uint32_t> hits(M);
+            if (M) {
+                HIPCHK(hipMemcpy(khi.data(), A + h.key_hi_off, M * 8, hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(klo.data(), A + h.key_lo_off, M * 8, hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(hits.data(), A + h.hits_off, M * 4, hipMemcpyDeviceToHost));
+            }
+            o.dbg_all_ranks = (mgpu_rank_t *)calloc(std::max<uint64_t>(M, 1), sizeof(mgpu_rank_t));
+            for (uint64_t j = 0; j < M; j++) { decode_key(h.kf, h.nkf, khi[j], klo[j], &o.dbg_all_ranks[j]); o.dbg_all_ranks[j].docid = hits[j]; }
+        }
+        // algorithmic bytes (DESIGN.md byte model)
+        const uint64_t B = (uint64_t)q.sh.W * 8;
+        c->stage_bytes[1] += h.scatter_docs * 4;
+        c->stage_bytes[2] += h.formula_rows * B + B + 4 * M;
+        if (h.k) c->stage_bytes[3] += M * (uint64_t)(4 + 8 + 8.0 * sh->avg_dw + (p.rank_by >= 0 ? 8 : 0) + 16);
+        {
+            double per = 0;
+            for (int f = 0; f < q.sh.num_facets; f++) if ((q.hist_mask >> f) & 1u) per += 4 + 8 + 4.0 * sh->avg_fv[f];
+            int na = 0; for (int a = 0; a < p.num_aggs; a++) if (p.agg_type[a] != MGPU_A_CARDINALITY) na++;
+            per += na * (4 + 8);
+            c->stage_bytes[4] += (uint64_t)(M * per);
+        }
+        for (int j = 0; j < h.nfac; j++) c->stage_bytes[5] += (uint64_t)q.sh.fa_nord[h.fac_field[j]] * 24;
+        if (h.k) c->stage_bytes[6] += 16 * M * (M > MG_SEL_FINAL ? 2 : 1);
+    }
+    c->stage_bytes[0] = up_bytes; c->stage_bytes[7] = res_bytes;
+    return worst;
+}
+
+// ------------------------------------------------------------------ primitives
+extern "C" int mgpu_posting_op(mgpu_ctx_t *c, mgpu_shard_t *s, int op, uint32_t pid_a, uint32_t pid_b,
+                               uint64_t *out_words, uint32_t nwords, uint64_t *card) {
+    if (!c || !s || op < 0 || op > 2) return fail(MGPU_E_ARG, "bad argument");
+    if (pid_a >= s->dev.num_postings || pid_b >= s->dev.num_postings) return fail(MGPU_E_ARG, "posting id out of range");
+    HIPCHK(hipSetDevice(c->device));
+    const ShardDev &sd = s->dev;
+    const size_t rowb = (size_t)sd.Wp * 8;
+    int rc = ensure_arena(c, rowb * 3 + 4096 + 2 * sizeof(ScatterItem) * ((size_t)sd.N / MG_SCATTER_CHUNK + 2));
+    if (rc) return rc;
+    char *A = c->arena.dev;
+    u64 *ra = (u64 *)A, *rb = (u64 *)(A + rowb), *ro = (u64 *)(A + 2 * rowb);
+    unsigned long long *dcard = (unsigned long long *)(A + 3 * rowb);
+    ScatterItem *ditems = (ScatterItem *)(A + 3 * rowb + 256);
+    hipStream_t st = c->stream;
+    HIPCHK(hipMemsetAsync(A, 0, 3 * rowb + 256, st));
+    std::vector<ScatterItem> items;
+    const u64 *srca = nullptr, *srcb = nullptr;
+    auto prep = [&](uint32_t pid, u64 *row, const u64 **src) {
+        int32_t di = s->post_dense[pid];
+        if (di >= 0) { *src = (const u64 *)sd.dense + (size_t)di * sd.Wp; return; }
+        *src = row;
+        uint64_t cnt = s->post_off[pid + 1] - s->post_off[pid];
+        for (uint64_t at = 0; at < cnt; at += MG_SCATTER_CHUNK) {
+            ScatterItem it; it.src = sd.post_doc + s->post_off[pid] + at; it.dst = (uint64_t *)row;
+            it.n = (uint32_t)std::min<uint64_t>(MG_SCATTER_CHUNK, cnt - at); it.pad = 0;
+            items.push_back(it);
+        }
+    };
+    prep(pid_a, ra, &srca); prep(pid_b, rb, &srcb);
+    if (!items.empty()) {
+        HIPCHK(hipMemcpyAsync(ditems, items.data(), items.size() * sizeof(ScatterItem), hipMemcpyHostToDevice, st));
+        mgk_scatter(st, ditems, (uint32_t)items.size());
+    }
+    mgk_row_op(st, srca, srcb, ro, sd.W, op, dcard);
+    unsigned long long hc = 0;
+    HIPCHK(hipMemcpyAsync(&hc, dcard, 8, hipMemcpyDeviceToHost, st));
+    if (out_words) {
+        if (nwords < sd.W) return fail(MGPU_E_ARG, "output buffer too small");
+        HIPCHK(hipMemcpyAsync(out_words, ro, (size_t)sd.W * 8, hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    if (card) *card = hc;
+    return MGPU_OK;
+}

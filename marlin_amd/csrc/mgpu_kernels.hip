@@ -1,0 +1,802 @@
+// mgpu_kernels.hip -- gfx950 (CDNA4, wave64) kernels of the shard-query path.
+//
+// All kernels are HBM/L2-bound integer work: 8-16 B per lane coalesced streams over dense
+// u64 bitmap rows, wave-level popcount / ballot compaction, LDS-privatised histograms and an
+// LDS bitonic stage for the final top-k.  No MFMA: nothing here is a dense contraction.
+// blockIdx.y always selects the (shard, query) pair ("squery") of a batch.
+#include <hip/hip_runtime.h>
+#include "mgpu_types.h"
+
+typedef unsigned long long u64;
+typedef unsigned __int128 u128;
+
+// ------------------------------------------------------------------ helpers
+__device__ __forceinline__ u64 wave_or64(u64 v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// exclusive scan of one u32 per thread over a 256-thread block; returns the block total in *total
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *total, uint32_t *lds /* >= 8 */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) lds[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < MG_BLOCK / 64; w++) {
+        uint32_t s = lds[w];
+        if (w < wave) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + incl - v;
+}
+
+// ------------------------------------------------------------------ scatter (sparse postings -> rows)
+// oper_or's array half (cont.c:431-435 array_cont_inplace_union) and num_*_filter's bmap_add
+// loop (filter_apply.c:44-54,159-166,182-191): sorted docid lists OR-ed into a zeroed dense row.
+// Lanes that hit the same u64 word are merged in-wave first, so one atomic goes out per word.
+__global__ __launch_bounds__(MG_BLOCK) void k_scatter(const ScatterItem *items, uint32_t nitems) {
+    for (uint32_t it = blockIdx.x; it < nitems; it += gridDim.x) {
+        const ScatterItem s = items[it];
+        for (uint32_t base = 0; base < s.n; base += MG_BLOCK) {
+            uint32_t i = base + threadIdx.x;
+            bool valid = i < s.n;
+            uint32_t d = valid ? s.src[i] : 0xFFFFFFFFu;
+            uint32_t w = d >> 6;
+            u64 bit = valid ? (1ull << (d & 63)) : 0ull;
+            // sorted input: equal words are adjacent lanes; segmented OR by doubling
+            const int lane = threadIdx.x & 63;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                uint32_t ow = __shfl_down(w, o, 64);
+                u64 ob = __shfl_down(bit, o, 64);
+                if (lane + o < 64 && ow == w) bit |= ob;
+            }
+            uint32_t pw = __shfl_up(w, 1, 64);
+            bool head = (lane == 0) || (pw != w);
+            if (valid && head) atomicOr((u64 *)&s.dst[w], bit);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ formula + filter + popcount
+__device__ __forceinline__ u64 term_word(const SqDev &sq, const uint32_t *blob, int t, uint32_t w) {
+    u64 v = 0;
+    const int r = sq.term_row[t];
+    if (r >= 0) v = sq.rows[(size_t)r * sq.sh.Wp + w];
+    const uint32_t e = sq.term_dense_off[t + 1];
+    for (uint32_t i = sq.term_dense_off[t]; i < e; i++) v |= sq.sh.dense[(size_t)blob[i] * sq.sh.Wp + w];
+    return v;
+}
+
+// get_matching_docids (squery.c:212-277) fused with squery_apply_filters (squery.c:377-395,
+// filter_apply.c:207-227) and bmap_cardinality (bmap.c:362-368): one u64 word per lane.
+__global__ __launch_bounds__(MG_BLOCK) void k_formula(const SqDev *sqs, const uint32_t *blob) {
+    const SqDev &sq = sqs[blockIdx.y];
+    if (blockIdx.x >= sq.nblk) return;
+    __shared__ uint32_t red[MG_BLOCK / 64];
+    const uint32_t w = blockIdx.x * MG_WORDS_PER_BLOCK + threadIdx.x;
+    u64 v = 0;
+    if (w < sq.sh.W && !sq.empty) {
+        const int nt = sq.num_terms;
+        if (nt == 1) {
+            v = term_word(sq, blob, 0, w);
+        } else if (nt == 3) {
+            v = (term_word(sq, blob, 0, w) & term_word(sq, blob, 1, w)) | term_word(sq, blob, 2, w);
+        } else {
+            u64 acc = ~0ull, prev = 0;
+            for (int i = 0; i < nt; i += 2) {
+                u64 g = prev | term_word(sq, blob, i, w);
+                u64 next = 0;
+                if (i < nt - 2) { next = term_word(sq, blob, i + 1, w); g |= next; }
+                acc &= g;
+                prev = next;
+            }
+            v = acc | term_word(sq, blob, nt - 1, w);
+        }
+        if (sq.num_fops > 0) {
+            // postfix filter program on a small register stack (static indexing only)
+            u64 s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0;
+            const uint32_t *ops = blob + sq.fops_off;
+            for (int i = 0; i < sq.num_fops; i++) {
+                const int op = (int)ops[i * 2];
+                const int a = (int)ops[i * 2 + 1];
+                if (op <= MGPU_F_PUSH_EMPTY) {
+                    u64 x = 0;
+                    if (op != MGPU_F_PUSH_EMPTY)
+                        x = (a >= 0) ? sq.sh.dense[(size_t)a * sq.sh.Wp + w] : sq.rows[(size_t)(~a) * sq.sh.Wp + w];
+                    s7 = s6; s6 = s5; s5 = s4; s4 = s3; s3 = s2; s2 = s1; s1 = s0; s0 = x;
+                } else if (op == MGPU_F_DOCS_ANDNOT) {
+                    s0 = v & ~s0;
+                } else {
+                    s0 = (op == MGPU_F_AND) ? (s1 & s0) : (s1 | s0);
+                    s1 = s2; s2 = s3; s3 = s4; s4 = s5; s5 = s6; s6 = s7; s7 = 0;
+                }
+            }
+            v &= s0;
+        }
+    }
+    if (w < sq.sh.Wp) sq.docid_map[w] = v;
+    uint32_t c = wave_sum32((uint32_t)__popcll(v));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) sq.blk_cnt[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// exclusive scan of the per-block hit counts; one workgroup per squery
+__global__ __launch_bounds__(MG_BLOCK) void k_scan(const SqDev *sqs) {
+    const SqDev &sq = sqs[blockIdx.x];
+    __shared__ uint32_t lds[8];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < sq.nblk; base += MG_BLOCK) {
+        uint32_t i = base + threadIdx.x;
+        uint32_t v = (i < sq.nblk) ? sq.blk_cnt[i] : 0;
+        uint32_t tot;
+        uint32_t ex = block_excl_scan(v, &tot, lds);
+        uint32_t c = carry;
+        if (i < sq.nblk) sq.blk_cnt[i] = c + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *sq.num_hits = carry;
+}
+
+// bmap_iterate / cont_iterate (bmap.c:370-374, cont.c:590-610): bitmap -> ascending docid list
+__global__ __launch_bounds__(MG_BLOCK) void k_compact(const SqDev *sqs) {
+    const SqDev &sq = sqs[blockIdx.y];
+    if (blockIdx.x >= sq.nblk) return;
+    __shared__ uint32_t lds[8];
+    const uint32_t w = blockIdx.x * MG_WORDS_PER_BLOCK + threadIdx.x;
+    u64 v = (w < sq.sh.W) ? sq.docid_map[w] : 0;
+    uint32_t tot;
+    uint32_t off = sq.blk_cnt[blockIdx.x] + block_excl_scan((uint32_t)__popcll(v), &tot, lds);
+    uint32_t base = w << 6;
+    while (v) {
+        int b = __ffsll((long long)v) - 1;
+        v &= v - 1;
+        sq.hits[off++] = base + (uint32_t)b;
+    }
+}
+
+// ------------------------------------------------------------------ ranking
+struct RankOut { uint32_t typos, prox, field, pos, exact; };
+
+__device__ __forceinline__ uint32_t hash_wid(uint32_t h) {
+    h ^= h >> 16; h *= 0x7feb352dU; h ^= h >> 15; h *= 0x846ca68bU; h ^= h >> 16;
+    return h;
+}
+
+// insertion sort of packed (slot << 32 | position) pairs
+__device__ __forceinline__ void sort_pairs(u64 *p, int n) {
+    for (int i = 1; i < n; i++) {
+        u64 x = p[i];
+        int j = i - 1;
+        while (j >= 0 && p[j] > x) { p[j + 1] = p[j]; j--; }
+        p[j + 1] = x;
+    }
+}
+
+// the proximity walk of docrank.c:188-204 / 303-319 over two sorted runs inside p[]
+__device__ __forceinline__ int prox_walk(const u64 *p, int a0, int a1, int b0, int b1) {
+    int i = a0, j = b0, mindiff = 8;
+    while (i < a1 && j < b1) {
+        int pos1 = (int)(uint32_t)p[i], pos2 = (int)(uint32_t)p[j];
+        int diff = pos1 - pos2; if (diff < 0) diff = -diff;
+        if (diff != 0 && diff < mindiff) { mindiff = diff; if (mindiff == 1) break; }
+        if (pos1 > pos2) j++; else i++;
+    }
+    return mindiff;
+}
+
+// calculate_rank (docrank.c:338-369) for one document.  `pairs`/`cap` is the position scratch
+// (registers/private memory on the fast path, a slice of the global pool on the overflow path).
+// Returns false when the scratch overflowed.
+__device__ bool rank_doc(const SqDev &sq, const uint2 *htab, uint32_t hmask, uint32_t docid,
+                         u64 *pairs, int cap, RankOut &ro) {
+    const int nw = sq.num_words, nt = sq.num_terms;
+    const uint32_t e0 = sq.sh.dw_off[docid], e1 = sq.sh.dw_off[docid + 1];
+    const uint32_t pbase = sq.sh.pp_off[docid];
+    uint32_t exact_mask = 0;
+    u64 single_best = ~0ull;            // (dist << 40) | (priority << 32) | position, single-word queries
+    u64 typ_lo = ~0ull, typ_hi = ~0ull; // per-word typos, one byte each (0xFF = unmatched)
+    uint32_t prox1 = 0;                 // bit x: word x matched through a concatenated (odd) term
+    bool comb = false;                  // the all-words term matched
+    uint32_t bestpos = 0xFFFFFFFFu;
+    int np = 0;
+    bool ovf = false;
+
+    for (uint32_t e = e0; e < e1; e++) {
+        const uint2 wi = sq.sh.dw[e];
+        uint32_t val = 0; bool found = false;
+        for (uint32_t h = hash_wid(wi.x) & hmask;; h = (h + 1) & hmask) {
+            const uint2 s = htab[h];
+            if (s.x == wi.x) { val = s.y; found = true; break; }
+            if (s.x == 0) break;
+        }
+        if (!found) continue;
+        exact_mask |= val >> 16;
+        const uint32_t dist = val & 0xFF, mterm = (val >> 8) & 0xFF;
+        if (dist == 0xFF) continue;
+        const bool inl = wi.y & 1u;
+        const uint32_t cnt = inl ? 1u : ((wi.y >> 1) & 0xFFu);
+        const uint32_t poff = wi.y >> 9;
+        const uint32_t first = inl ? ((((wi.y >> 1) & 0xFFu) << 16) + poff) : sq.sh.pp[pbase + poff];
+        if (nw == 1) {
+            // rank_single_term (docrank.c:63-112): least distance, then least (field, position)
+            u64 k = ((u64)dist << 40) | (u64)first;      // first = (priority << 16) + position of the best occurrence
+            if (k < single_best) single_best = k;
+            continue;
+        }
+        int slot_a, slot_b = -1;
+        if (nw == 2) {
+            // rank_three_terms (docrank.c:125-209)
+            if (mterm == 2) comb = true;
+            else {
+                const int sh8 = (int)mterm * 8;
+                if (dist < ((typ_lo >> sh8) & 0xFF)) typ_lo = (typ_lo & ~(0xFFull << sh8)) | ((u64)dist << sh8);
+            }
+            slot_a = (int)mterm;
+        } else {
+            // rank_many_terms (docrank.c:218-328); term_to_word_idx's quirk reduces to term / 2
+            if ((int)mterm == nt - 1) comb = true;
+            const int widx = (int)mterm >> 1;
+            {
+                u64 &tw = widx < 8 ? typ_lo : typ_hi;
+                const int sh8 = (widx & 7) * 8;
+                if (dist < ((tw >> sh8) & 0xFF)) tw = (tw & ~(0xFFull << sh8)) | ((u64)dist << sh8);
+            }
+            slot_a = widx;
+            if (mterm & 1u) {
+                prox1 |= 1u << widx;
+                if ((int)mterm != nt - 1) {
+                    const int w1 = widx + 1;
+                    u64 &tw = w1 < 8 ? typ_lo : typ_hi;
+                    tw &= ~(0xFFull << ((w1 & 7) * 8));
+                    slot_b = w1;
+                }
+            }
+        }
+        if (first < bestpos) bestpos = first;          // runs are sorted: the first entry is the least
+        const bool keep_a = !(nw == 2 && slot_a == 2); // the pair term only feeds best_position
+        for (uint32_t j = 0; j < cnt; j++) {
+            const uint32_t p = inl ? first : sq.sh.pp[pbase + poff + j];
+            if (keep_a) { if (np < cap) pairs[np++] = ((u64)slot_a << 32) | p; else ovf = true; }
+            if (slot_b >= 0) { if (np < cap) pairs[np++] = ((u64)slot_b << 32) | p; else ovf = true; }
+        }
+        if (ovf) return false;
+    }
+
+    exact_mask &= sq.exact_present;
+    ro.exact = (uint32_t)__popc(exact_mask);
+    if (nw == 1) {
+        ro.prox = 0;
+        const bool ex = exact_mask & 1u;
+        uint32_t d = (uint32_t)(single_best >> 40);
+        if (single_best == ~0ull) d = 0xFF;
+        if (ex) {
+            ro.typos = 0;
+            if (d == 0) { ro.field = (uint32_t)(single_best >> 16) & 0xFF; ro.pos = (uint32_t)single_best & 0xFFFF; }
+            else { ro.field = 0xFF; ro.pos = 0xFFFF; }
+        } else if (d <= 0xFE) {
+            ro.typos = d; ro.field = (uint32_t)(single_best >> 16) & 0xFF; ro.pos = (uint32_t)single_best & 0xFFFF;
+        } else { ro.typos = 0xFF; ro.field = 0xFF; ro.pos = 0xFFFF; }
+        return true;
+    }
+    // typos: exact words and the all-words term zero them; the sum wraps like the reference's uint8_t
+    uint32_t tsum = 0;
+    for (int i = 0; i < nw; i++) {
+        uint32_t t = (uint32_t)(((i < 8 ? typ_lo : typ_hi) >> ((i & 7) * 8)) & 0xFF);
+        if (comb || ((exact_mask >> i) & 1u)) t = 0;
+        tsum += t;
+    }
+    ro.typos = tsum & 0xFF;
+    ro.field = (bestpos >> 16) & 0xFF;
+    ro.pos = bestpos & 0xFFFF;
+    if (comb) { ro.prox = (nw == 2) ? 1u : (uint32_t)(nw - 1); return true; }
+    sort_pairs(pairs, np);
+    // slot boundaries
+    uint32_t prox = 0;
+    int idx = 0;
+    int a0 = 0, a1 = 0;
+    while (idx < np && (int)(pairs[idx] >> 32) == 0) idx++;
+    a1 = idx;
+    for (int x = 0; x < nw - 1; x++) {
+        int b0 = a1, b1 = b0;
+        while (b1 < np && (int)(pairs[b1] >> 32) == x + 1) b1++;
+        if (nw > 2 && ((prox1 >> x) & 1u)) prox += 1;
+        else prox += (uint32_t)prox_walk(pairs, a0, a1, b0, b1);
+        a0 = b0; a1 = b1;
+    }
+    ro.prox = prox & 0xFFFF;
+    return true;
+}
+
+__device__ __forceinline__ u64 f64_order_key(double x) {
+    u64 u = (u64)__double_as_longlong(x);
+    return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+}
+
+__device__ __forceinline__ void build_key(const SqDev &sq, const RankOut &ro, double cmp, u64 &hi, u64 &lo) {
+    u128 key = 0;
+    for (int i = 0; i < sq.nkf; i++) {
+        const KeyField f = sq.kf[i];
+        u64 v;
+        switch (f.kind) {
+            case KF_TYPO: v = ro.typos; break;
+            case KF_PROX: v = ro.prox; break;
+            case KF_POS: v = ro.pos; break;
+            case KF_EXACT: v = 255u - ro.exact; break;
+            case KF_FIELD: v = ro.field; break;
+            case KF_COMP_DESC: v = ~f64_order_key(cmp); break;
+            default: v = f64_order_key(cmp); break;
+        }
+        key |= (u128)v << f.shift;
+    }
+    hi = (u64)(key >> 64); lo = (u64)key;
+}
+
+// perform_doc_rank (docrank.c:414-443) for every hit: one document per lane.
+template <bool OVF>
+__global__ __launch_bounds__(MG_BLOCK) void k_rank(const SqDev *sqs, const uint32_t *blob,
+                                                   u64 *pool, uint32_t *pool_used, uint64_t pool_cap) {
+    const SqDev &sq = sqs[blockIdx.y];
+    const uint32_t M = OVF ? *sq.ovf_cnt : *sq.num_hits;
+    if (blockIdx.x * MG_BLOCK >= M) return;
+    __shared__ uint2 lds_tab[MG_LDS_HASH];
+    const uint2 *gtab = (const uint2 *)(blob + sq.hash_off);
+    const uint32_t hmask = sq.hash_mask;
+    const uint2 *htab = gtab;
+    if (sq.do_rank && hmask < MG_LDS_HASH) {
+        for (uint32_t i = threadIdx.x; i <= hmask; i += MG_BLOCK) lds_tab[i] = gtab[i];
+        __syncthreads();
+        htab = lds_tab;
+    }
+    const uint32_t t = blockIdx.x * MG_BLOCK + threadIdx.x;
+    u64 hi = 0, lo = 0;
+    bool have = false;
+    if (t < M) {
+        const uint32_t hidx = OVF ? sq.ovf_list[t] : t;
+        const uint32_t docid = sq.hits[hidx];
+        RankOut ro = {0, 0, 0, 0, 0};
+        bool ok = true;
+        if (sq.do_rank) {
+            if (!OVF) {
+                u64 pairs[MG_PCAP];
+                ok = rank_doc(sq, htab, hmask, docid, pairs, MG_PCAP, ro);
+                if (!ok) sq.ovf_list[atomicAdd(sq.ovf_cnt, 1u)] = hidx;
+            } else {
+                // bound of the pairs a document can produce: twice its token count
+                const uint32_t ntok = (sq.sh.dw_off[docid + 1] - sq.sh.dw_off[docid]) +
+                                      (sq.sh.pp_off[docid + 1] - sq.sh.pp_off[docid]);
+                const uint32_t need = 2 * ntok + 2;
+                const uint32_t at = atomicAdd(pool_used, need);
+                if ((uint64_t)at + need > pool_cap) { atomicMax(sq.err, (uint32_t)(-MGPU_E_SCRATCH)); ok = false; }
+                else ok = rank_doc(sq, htab, hmask, docid, pool + at, (int)need, ro);
+            }
+        }
+        if (ok) {
+            const double cmp = (sq.rank_by >= 0) ? sq.sh.num_col[sq.rank_by][docid] : 0.0;
+            build_key(sq, ro, cmp, hi, lo);
+            sq.key_hi[hidx] = hi; sq.key_lo[hidx] = lo;
+            have = true;
+        }
+    }
+    // bits that differ between keys: OR of keys and OR of complements
+    u64 a = have ? hi : 0, b = have ? lo : 0, na = have ? ~hi : 0, nb = have ? ~lo : 0;
+    a = wave_or64(a); b = wave_or64(b); na = wave_or64(na); nb = wave_or64(nb);
+    if ((threadIdx.x & 63) == 0) {
+        atomicOr((u64 *)&sq.key_andor[0], na); atomicOr((u64 *)&sq.key_andor[1], nb);
+        atomicOr((u64 *)&sq.key_andor[2], a);  atomicOr((u64 *)&sq.key_andor[3], b);
+    }
+}
+
+// ------------------------------------------------------------------ facets + aggregations
+// process_facet_result (docrank.c:371-389) and consume_*_agg (metric-aggs.c) over the hit list.
+// Facet ids were turned into dense ordinals by the mirror, so the hashtable of hashtable.c
+// becomes a histogram: privatised in LDS when the field has <= MG_LDS_HIST values.
+__global__ __launch_bounds__(MG_BLOCK) void k_docproc(const SqDev *sqs) {
+    const SqDev &sq = sqs[blockIdx.y];
+    if (blockIdx.x >= sq.nproc_blocks) return;
+    const uint32_t M = *sq.num_hits;
+    __shared__ uint32_t hist[MG_LDS_HIST];
+    __shared__ AggPart red[MG_BLOCK / 64];
+    const uint32_t stride = sq.nproc_blocks * MG_BLOCK;
+    const uint32_t t0 = blockIdx.x * MG_BLOCK + threadIdx.x;
+
+    for (int f = 0; f < sq.sh.num_facets; f++) {
+        if (!((sq.hist_mask >> f) & 1u)) continue;
+        const uint32_t nord = sq.sh.fa_nord[f];
+        const uint32_t *off = sq.sh.fa_off[f];
+        const uint32_t *ord = sq.sh.fa_ord[f];
+        uint32_t *gh = sq.hist[f];
+        const bool use_lds = nord <= MG_LDS_HIST;
+        if (use_lds) {
+            for (uint32_t i = threadIdx.x; i < nord; i += MG_BLOCK) hist[i] = 0;
+            __syncthreads();
+        }
+        for (uint32_t i = t0; i < M; i += stride) {
+            const uint32_t d = sq.hits[i];
+            const uint32_t a = off[d], b = off[d + 1];
+            for (uint32_t j = a; j < b; j++) {
+                const uint32_t o = ord[j];
+                if (use_lds) atomicAdd(&hist[o], 1u); else atomicAdd(&gh[o], 1u);
+            }
+        }
+        if (use_lds) {
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < nord; i += MG_BLOCK) {
+                const uint32_t c = hist[i];
+                if (c) atomicAdd(&gh[i], c);
+            }
+            __syncthreads();
+        }
+    }
+
+    for (int a = 0; a < sq.num_aggs; a++) {
+        if (sq.agg_type[a] == MGPU_A_CARDINALITY) continue;
+        const double *col = sq.sh.num_col[sq.agg_field[a]];
+        double sum = 0.0, mn = 1.7976931348623157e308, mx = -1.7976931348623157e308;
+        unsigned long long cnt = 0;
+        for (uint32_t i = t0; i < M; i += stride) {
+            const double v = col[sq.hits[i]];
+            if (v != -1.7976931348623157e308) {          // get_num_value's "no value" marker, metric-aggs.c:106,149
+                sum += v; mn = v < mn ? v : mn; mx = v > mx ? v : mx; cnt++;
+            }
+        }
+        // fixed-shape tree: lanes, then waves, so the f64 sum is reproducible run to run
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double s2 = __shfl_down(sum, o, 64), n2 = __shfl_down(mn, o, 64), x2 = __shfl_down(mx, o, 64);
+            const unsigned long long c2 = __shfl_down(cnt, o, 64);
+            sum += s2; mn = n2 < mn ? n2 : mn; mx = x2 > mx ? x2 : mx; cnt += c2;
+        }
+        if ((threadIdx.x & 63) == 0) { AggPart p = {sum, mn, mx, cnt}; red[threadIdx.x >> 6] = p; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            AggPart p = red[0];
+            for (int w = 1; w < MG_BLOCK / 64; w++) {
+                p.sum += red[w].sum; p.mn = red[w].mn < p.mn ? red[w].mn : p.mn;
+                p.mx = red[w].mx > p.mx ? red[w].mx : p.mx; p.cnt += red[w].cnt;
+            }
+            sq.agg_part[(size_t)blockIdx.x * sq.num_aggs + a] = p;
+        }
+        __syncthreads();
+    }
+}
+
+// combines the per-block partials in block order; one wave per squery
+__global__ __launch_bounds__(64) void k_aggfinal(const SqDev *sqs) {
+    const SqDev &sq = sqs[blockIdx.x];
+    const int a = threadIdx.x;
+    if (a >= sq.num_aggs || sq.agg_type[a] == MGPU_A_CARDINALITY) return;
+    AggPart p = {0.0, 1.7976931348623157e308, -1.7976931348623157e308, 0};
+    for (uint32_t b = 0; b < sq.nproc_blocks; b++) {
+        const AggPart q = sq.agg_part[(size_t)b * sq.num_aggs + a];
+        p.sum += q.sum; p.mn = q.mn < p.mn ? q.mn : p.mn; p.mx = q.mx > p.mx ? q.mx : p.mx; p.cnt += q.cnt;
+    }
+    sq.agg_out[a] = p;
+}
+
+// facet bins -> selection keys: smaller key = larger count, ties by facet id (squery.c:411-437)
+struct FkJob { const uint32_t *hist; const uint32_t *ord2id; uint32_t n; uint32_t pad; u64 *key_hi, *key_lo; };
+__global__ __launch_bounds__(MG_BLOCK) void k_fkeys(const FkJob *jobs) {
+    const FkJob j = jobs[blockIdx.y];
+    for (uint32_t i = blockIdx.x * MG_BLOCK + threadIdx.x; i < j.n; i += gridDim.x * MG_BLOCK) {
+        const uint32_t c = j.hist[i];
+        j.key_hi[i] = c ? (u64)(0xFFFFFFFFu - c) : ~0ull;
+        j.key_lo[i] = j.ord2id[i];
+    }
+}
+
+// distinct facet ids among the hits (cardinality agg, metric-aggs.c:23-45,47-55): nonzero bins
+struct CardJob { const uint32_t *hist; const uint32_t *ord2id; uint32_t n; uint32_t pad; uint32_t *out_ids; uint32_t *out_n; };
+__global__ __launch_bounds__(MG_BLOCK) void k_card(const CardJob *jobs) {
+    const CardJob j = jobs[blockIdx.y];
+    for (uint32_t base = blockIdx.x * MG_BLOCK; base < j.n; base += gridDim.x * MG_BLOCK) {
+        const uint32_t i = base + threadIdx.x;
+        const bool nz = (i < j.n) && j.hist[i] != 0;
+        const u64 m = __ballot(nz);
+        const int lane = threadIdx.x & 63;
+        uint32_t wbase = 0;
+        if (lane == 0 && m) wbase = atomicAdd(j.out_n, (uint32_t)__popcll(m));
+        wbase = __shfl(wbase, 0, 64);
+        if (nz) j.out_ids[wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = j.ord2id[i];
+    }
+}
+
+// ------------------------------------------------------------------ top-k selection
+// Replaces rank_partial_sort + rank_sort (sort.c:134-214) and ks_partialsort over facets
+// (squery.c:434): MSB-first radix select over only the key bits that differ between keys
+// (plus the index, so ties resolve to the lowest docid / facet id), 11 bits per pass, with the
+// candidate list compacted on every pass; a single workgroup then bitonic-sorts what is left.
+__device__ __forceinline__ uint32_t key_bit(u64 hi, u64 lo, uint32_t idx, uint32_t b) {
+    if (b < 64) return (uint32_t)(hi >> (63 - b)) & 1u;
+    if (b < 128) return (uint32_t)(lo >> (127 - b)) & 1u;
+    return (idx >> (159 - b)) & 1u;
+}
+__device__ __forceinline__ bool mask_bit(u64 mhi, u64 mlo, uint32_t midx, uint32_t b) {
+    return key_bit(mhi, mlo, midx, b) != 0;
+}
+// positions of the next MG_SEL_DIGIT varying bits at or after `from`; returns how many, *next = scan position after
+__device__ __forceinline__ int digit_bits(u64 mhi, u64 mlo, uint32_t midx, uint32_t from, uint8_t *pos, uint32_t *next) {
+    int n = 0;
+    uint32_t b = from;
+    for (; b < 160 && n < MG_SEL_DIGIT; b++) if (mask_bit(mhi, mlo, midx, b)) pos[n++] = (uint8_t)b;
+    *next = b;
+    return n;
+}
+__device__ __forceinline__ uint32_t digit_of(u64 hi, u64 lo, uint32_t idx, const uint8_t *pos, int n) {
+    uint32_t d = 0;
+    for (int j = 0; j < n; j++) d = (d << 1) | key_bit(hi, lo, idx, pos[j]);
+    return d;
+}
+__device__ __forceinline__ void job_masks(const SelJob &job, uint32_t M, u64 &mhi, u64 &mlo, uint32_t &midx) {
+    if (job.mask) { mhi = job.mask[2] & job.mask[0]; mlo = job.mask[3] & job.mask[1]; }
+    else { mhi = ~0ull; mlo = ~0ull; }
+    midx = (M > 1) ? (0xFFFFFFFFu >> __clz(M - 1)) : 0u;
+}
+
+#define SEL_ITEMS 8
+// extra ctl words used by the passes
+enum { SEL_NIN = SEL_NCAND, SEL_DSTAR = SEL_NEXT, SEL_BPREV = 8, SEL_NOUT = 9, SEL_BUF = 10, SEL_NPREV = 11 };
+
+__global__ __launch_bounds__(MG_BLOCK) void k_select_pass(const SelJob *jobs) {
+    const SelJob job = jobs[blockIdx.y];
+    uint32_t *ctl = job.ctl;
+    const uint32_t M = *job.m_ptr;
+    if (ctl[SEL_DONE]) return;
+    const uint32_t pass = ctl[SEL_PASS];
+    const uint32_t nin = (pass == 0) ? M : ctl[SEL_NIN];
+    const uint32_t krem = (pass == 0) ? job.k : ctl[SEL_KREM];
+    if (pass == 0 && (M <= MG_SEL_FINAL || job.k >= M)) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) { ctl[SEL_NIN] = M; ctl[SEL_KREM] = job.k; ctl[SEL_DONE] = 1; }
+        return;
+    }
+    const uint32_t per_block = MG_BLOCK * SEL_ITEMS;
+    const uint32_t nb_active = (nin + per_block - 1) / per_block;
+    if (blockIdx.x >= nb_active) return;
+
+    __shared__ uint32_t hist[MG_SEL_BINS];
+    __shared__ uint32_t s_last;
+    for (uint32_t i = threadIdx.x; i < MG_SEL_BINS; i += MG_BLOCK) hist[i] = 0;
+
+    u64 mhi, mlo; uint32_t midx;
+    job_masks(job, M, mhi, mlo, midx);
+    uint8_t pprev[MG_SEL_DIGIT], pcur[MG_SEL_DIGIT];
+    int nprev = 0; uint32_t dummy;
+    const uint32_t bitpos = (pass == 0) ? 0 : ctl[SEL_BITPOS];
+    if (pass > 0) nprev = digit_bits(mhi, mlo, midx, ctl[SEL_BPREV], pprev, &dummy);
+    uint32_t next_bitpos;
+    const int ncur = digit_bits(mhi, mlo, midx, bitpos, pcur, &next_bitpos);
+    const uint32_t dstar = ctl[SEL_DSTAR];
+    const uint32_t buf = ctl[SEL_BUF];
+    const uint32_t *rin = (pass <= 1) ? nullptr : job.cand[buf];
+    uint32_t *rout = job.cand[buf ^ (pass <= 1 ? 0u : 1u)];
+    uint32_t *win = job.out_idx;        // winners accumulate in the output buffer, sorted at the end
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    for (int it = 0; it < SEL_ITEMS; it++) {
+        const uint32_t i = blockIdx.x * per_block + it * MG_BLOCK + threadIdx.x;
+        bool keep = false, winner = false;
+        uint32_t idx = 0; u64 hi = 0, lo = 0;
+        if (i < nin) {
+            idx = rin ? rin[i] : i;
+            hi = job.key_hi[idx]; lo = job.key_lo[idx];
+            keep = true;
+            if (pass > 0) {
+                const uint32_t dp = digit_of(hi, lo, idx, pprev, nprev);
+                if (dp < dstar) { winner = true; keep = false; }
+                else if (dp > dstar) keep = false;
+            }
+        }
+        if (pass > 0) {
+            // wave-aggregated appends
+            const u64 mk = __ballot(keep), mw = __ballot(winner);
+            uint32_t bk = 0, bw = 0;
+            if (lane == 0) {
+                if (mk) bk = atomicAdd(&ctl[SEL_NOUT], (uint32_t)__popcll(mk));
+                if (mw) bw = atomicAdd(&ctl[SEL_NWIN], (uint32_t)__popcll(mw));
+            }
+            bk = __shfl(bk, 0, 64); bw = __shfl(bw, 0, 64);
+            const u64 below = (1ull << lane) - 1;
+            if (keep) rout[bk + (uint32_t)__popcll(mk & below)] = idx;
+            if (winner) win[bw + (uint32_t)__popcll(mw & below)] = idx;
+        }
+        if (keep) atomicAdd(&hist[digit_of(hi, lo, idx, pcur, ncur)], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < MG_SEL_BINS; i += MG_BLOCK) {
+        const uint32_t c = hist[i];
+        if (c) atomicAdd(&job.hist[i], c);
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (atomicAdd(&ctl[SEL_TICKET], 1u) == nb_active - 1) ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    // last workgroup of this pass: pick the digit that holds the krem-th smallest candidate
+    __threadfence();
+    uint32_t krem_now = krem;
+    if (pass > 0) {
+        // winners appended during this pass are exactly those below the previous digit
+        krem_now = job.k - __hip_atomic_load(&ctl[SEL_NWIN], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const uint32_t nkept = (pass == 0) ? M : __hip_atomic_load(&ctl[SEL_NOUT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (uint32_t i = threadIdx.x; i < MG_SEL_BINS; i += MG_BLOCK)
+        hist[i] = __hip_atomic_load(&job.hist[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0, d = 0;
+        const uint32_t nbins = 1u << ncur;
+        for (; d < nbins; d++) { if (acc + hist[d] >= krem_now) break; acc += hist[d]; }
+        if (d >= nbins) d = nbins - 1;
+        ctl[SEL_DSTAR] = d;
+        ctl[SEL_BPREV] = bitpos;
+        ctl[SEL_BITPOS] = next_bitpos;
+        ctl[SEL_KREM] = krem_now;
+        ctl[SEL_NIN] = nkept;
+        ctl[SEL_NOUT] = 0;
+        ctl[SEL_TICKET] = 0;
+        ctl[SEL_NPREV] = (uint32_t)ncur;
+        if (pass >= 1) ctl[SEL_BUF] = buf ^ (pass == 1 ? 0u : 1u);
+        ctl[SEL_PASS] = pass + 1;
+        // the list the final kernel reads is small enough once a pass kept <= MG_SEL_FINAL
+        if (pass > 0 && nkept <= MG_SEL_FINAL) ctl[SEL_DONE] = 1;
+    }
+    for (uint32_t i = threadIdx.x; i < MG_SEL_BINS; i += MG_BLOCK) job.hist[i] = 0;
+}
+
+struct SelOut { u64 *out_hi, *out_lo; uint32_t *out_pl; const uint32_t *payload; };
+
+// final stage: one workgroup per job sorts winners + remaining candidates and emits the top k
+__global__ __launch_bounds__(MG_BLOCK) void k_select_final(const SelJob *jobs, const SelOut *outs) {
+    const SelJob job = jobs[blockIdx.x];
+    const SelOut out = outs[blockIdx.x];
+    const uint32_t *ctl = job.ctl;
+    const uint32_t M = *job.m_ptr;
+    constexpr int CAP = 2 * MG_SEL_FINAL;
+    __shared__ u64 s_hi[CAP];
+    __shared__ u64 s_lo[CAP];
+    __shared__ uint32_t s_ix[CAP];
+    __shared__ uint32_t s_n;
+    if (!ctl[SEL_DONE]) { if (threadIdx.x == 0) *job.out_n = 0xFFFFFFFFu; return; }   // host launches more passes
+    const uint32_t pass = ctl[SEL_PASS];
+    const uint32_t nin = ctl[SEL_NIN];
+    const uint32_t nwin = ctl[SEL_NWIN];
+    u64 mhi, mlo; uint32_t midx;
+    job_masks(job, M, mhi, mlo, midx);
+    uint8_t pprev[MG_SEL_DIGIT]; int nprev = 0; uint32_t dummy;
+    if (pass > 0) nprev = digit_bits(mhi, mlo, midx, ctl[SEL_BPREV], pprev, &dummy);
+    const uint32_t dstar = ctl[SEL_DSTAR];
+    const uint32_t *rin = (pass <= 1) ? nullptr : job.cand[ctl[SEL_BUF]];
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    // winners found by the passes
+    for (uint32_t i = threadIdx.x; i < nwin; i += MG_BLOCK) {
+        const uint32_t idx = job.out_idx[i];
+        const uint32_t p = atomicAdd(&s_n, 1u);
+        s_hi[p] = job.key_hi[idx]; s_lo[p] = job.key_lo[idx]; s_ix[p] = idx;
+    }
+    // the last candidate list, with the last decision applied
+    for (uint32_t i = threadIdx.x; i < nin; i += MG_BLOCK) {
+        const uint32_t idx = rin ? rin[i] : i;
+        const u64 hi = job.key_hi[idx], lo = job.key_lo[idx];
+        bool take = true;
+        if (pass > 0) take = digit_of(hi, lo, idx, pprev, nprev) <= dstar;
+        if (take) {
+            const uint32_t p = atomicAdd(&s_n, 1u);
+            if (p < CAP) { s_hi[p] = hi; s_lo[p] = lo; s_ix[p] = idx; }
+        }
+    }
+    __syncthreads();
+    uint32_t n = s_n < CAP ? s_n : CAP;
+    uint32_t np2 = 1; while (np2 < n) np2 <<= 1;
+    for (uint32_t i = n + threadIdx.x; i < np2; i += MG_BLOCK) { s_hi[i] = ~0ull; s_lo[i] = ~0ull; s_ix[i] = 0xFFFFFFFFu; }
+    __syncthreads();
+    // bitonic sort ascending by (hi, lo, idx)
+    for (uint32_t k = 2; k <= np2; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < np2; i += MG_BLOCK) {
+                const uint32_t l = i ^ j;
+                if (l > i) {
+                    const bool up = (i & k) == 0;
+                    const u64 ah = s_hi[i], al = s_lo[i], bh = s_hi[l], bl = s_lo[l];
+                    const uint32_t ai = s_ix[i], bi = s_ix[l];
+                    const bool gt = (ah > bh) || (ah == bh && (al > bl || (al == bl && ai > bi)));
+                    if (gt == up) { s_hi[i] = bh; s_lo[i] = bl; s_ix[i] = bi; s_hi[l] = ah; s_lo[l] = al; s_ix[l] = ai; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    uint32_t kk = job.k < n ? job.k : n;
+    __shared__ uint32_t s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < kk; i += MG_BLOCK) {
+        if (job.skip_ones && s_hi[i] == ~0ull) continue;
+        out.out_hi[i] = s_hi[i]; out.out_lo[i] = s_lo[i];
+        out.out_pl[i] = out.payload ? out.payload[s_ix[i]] : s_ix[i];
+        atomicAdd(&s_cnt, 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *job.out_n = s_cnt;
+}
+
+// ------------------------------------------------------------------ primitives for the parity tests
+// bmap_and / bmap_andnot / oper_or + cardinality on two materialised rows
+__global__ __launch_bounds__(MG_BLOCK) void k_row_op(const u64 *a, const u64 *b, u64 *out, uint32_t W, int op,
+                                                     unsigned long long *card) {
+    uint32_t c = 0;
+    for (uint32_t w = blockIdx.x * MG_BLOCK + threadIdx.x; w < W; w += gridDim.x * MG_BLOCK) {
+        const u64 x = a[w], y = b[w];
+        const u64 v = (op == 0) ? (x & y) : (op == 1) ? (x | y) : (x & ~y);
+        out[w] = v;
+        c += (uint32_t)__popcll(v);
+    }
+    c = wave_sum32(c);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(card, (unsigned long long)c);
+}
+
+// ------------------------------------------------------------------ launch wrappers (called from mgpu_api.hip)
+extern "C" {
+void mgk_scatter(hipStream_t st, const ScatterItem *items, uint32_t nitems) {
+    if (!nitems) return;
+    uint32_t grid = nitems < 8192 ? nitems : 8192;
+    hipLaunchKernelGGL(k_scatter, dim3(grid), dim3(MG_BLOCK), 0, st, items, nitems);
+}
+void mgk_formula(hipStream_t st, const SqDev *sqs, const uint32_t *blob, uint32_t max_nblk, uint32_t nsq) {
+    hipLaunchKernelGGL(k_formula, dim3(max_nblk, nsq), dim3(MG_BLOCK), 0, st, sqs, blob);
+    hipLaunchKernelGGL(k_scan, dim3(nsq), dim3(MG_BLOCK), 0, st, sqs);
+    hipLaunchKernelGGL(k_compact, dim3(max_nblk, nsq), dim3(MG_BLOCK), 0, st, sqs);
+}
+void mgk_rank(hipStream_t st, const SqDev *sqs, const uint32_t *blob, uint32_t max_n, uint32_t nsq,
+              unsigned long long *pool, uint32_t *pool_used, uint64_t pool_cap) {
+    uint32_t gx = (max_n + MG_BLOCK - 1) / MG_BLOCK;
+    hipLaunchKernelGGL(k_rank<false>, dim3(gx, nsq), dim3(MG_BLOCK), 0, st, sqs, blob, pool, pool_used, pool_cap);
+    hipLaunchKernelGGL(k_rank<true>, dim3(gx, nsq), dim3(MG_BLOCK), 0, st, sqs, blob, pool, pool_used, pool_cap);
+}
+void mgk_docproc(hipStream_t st, const SqDev *sqs, uint32_t max_pblocks, uint32_t nsq) {
+    hipLaunchKernelGGL(k_docproc, dim3(max_pblocks, nsq), dim3(MG_BLOCK), 0, st, sqs);
+    hipLaunchKernelGGL(k_aggfinal, dim3(nsq), dim3(64), 0, st, sqs);
+}
+void mgk_fkeys(hipStream_t st, const void *jobs, uint32_t njobs, uint32_t max_n) {
+    if (!njobs) return;
+    uint32_t gx = (max_n + MG_BLOCK - 1) / MG_BLOCK; if (gx > 256) gx = 256; if (!gx) gx = 1;
+    hipLaunchKernelGGL(k_fkeys, dim3(gx, njobs), dim3(MG_BLOCK), 0, st, (const FkJob *)jobs);
+}
+void mgk_card(hipStream_t st, const void *jobs, uint32_t njobs, uint32_t max_n) {
+    if (!njobs) return;
+    uint32_t gx = (max_n + MG_BLOCK - 1) / MG_BLOCK; if (gx > 256) gx = 256; if (!gx) gx = 1;
+    hipLaunchKernelGGL(k_card, dim3(gx, njobs), dim3(MG_BLOCK), 0, st, (const CardJob *)jobs);
+}
+void mgk_select(hipStream_t st, const SelJob *jobs, const void *outs, uint32_t njobs, uint32_t max_m, int passes) {
+    if (!njobs) return;
+    uint32_t gx = (max_m + MG_BLOCK * SEL_ITEMS - 1) / (MG_BLOCK * SEL_ITEMS); if (!gx) gx = 1;
+    for (int p = 0; p < passes; p++)
+        hipLaunchKernelGGL(k_select_pass, dim3(gx, njobs), dim3(MG_BLOCK), 0, st, jobs);
+    hipLaunchKernelGGL(k_select_final, dim3(njobs), dim3(MG_BLOCK), 0, st, jobs, (const SelOut *)outs);
+}
+void mgk_row_op(hipStream_t st, const unsigned long long *a, const unsigned long long *b, unsigned long long *out,
+                uint32_t W, int op, unsigned long long *card) {
+    uint32_t gx = (W + MG_BLOCK - 1) / MG_BLOCK; if (gx > 2048) gx = 2048; if (!gx) gx = 1;
+    hipLaunchKernelGGL(k_row_op, dim3(gx), dim3(MG_BLOCK), 0, st, a, b, out, W, op, card);
+}
+}

@@ -1,0 +1,117 @@
+// mgpu_types.h -- structures shared by the host runtime and the gfx950 kernels.
+#pragma once
+#include <stdint.h>
+#include "marlin_gpu.h"
+
+#define MG_BLOCK        256          // threads per workgroup (4 waves of 64)
+#define MG_WORDS_PER_BLOCK 256       // u64 bitmap words handled by one formula/compact block
+#define MG_MAX_STACK    8            // filter program stack depth
+#define MG_PCAP         24           // in-register (slot,position) pairs per document before overflow
+#define MG_SEL_BINS     2048         // radix-select digit = 11 bits
+#define MG_SEL_DIGIT    11
+#define MG_SEL_PASSES   6            // fixed number of launched select passes (66 varying bits)
+#define MG_SEL_FINAL    2048         // candidates sorted by the final block
+#define MG_SCATTER_CHUNK 2048        // docids per scatter work item
+#define MG_LDS_HASH     4096         // wid table slots staged in LDS (32 KiB)
+#define MG_LDS_HIST     8192         // facet bins privatised in LDS (32 KiB)
+
+// Device view of one shard mirror.
+struct ShardDev {
+    uint32_t N;                      // bits per row = max_docid + 1
+    uint32_t W;                      // u64 words per row
+    uint32_t Wp;                     // row stride in u64 words (multiple of 32 = 256 B)
+    uint32_t num_postings;
+    const uint64_t *dense;           // [n_dense][Wp]
+    const int32_t  *post_dense;      // [num_postings] dense row index or -1
+    const uint64_t *post_off;        // [num_postings + 1] into post_doc (sparse postings only)
+    const uint32_t *post_doc;
+    // docwords: CSR over docids; entry = {wid, info}; info bit0 = single position inline
+    const uint32_t *dw_off;          // [N + 1]
+    const uint2    *dw;              // {wid, info}
+    const uint32_t *pp_off;          // [N + 1] decoded position pool ((priority << 16) + position)
+    const uint32_t *pp;
+    // facets
+    int32_t  num_facets, num_numbers;
+    const uint32_t *fa_off[MGPU_MAX_FIELDS];    // [N + 1]
+    const uint32_t *fa_ord[MGPU_MAX_FIELDS];    // dense ordinals
+    const uint32_t *fa_ord2id[MGPU_MAX_FIELDS]; // ordinal -> facet id
+    uint32_t fa_nord[MGPU_MAX_FIELDS];
+    // numbers
+    const double   *num_col[MGPU_MAX_FIELDS];   // [N]
+    const uint32_t *np_doc[MGPU_MAX_FIELDS];
+};
+
+// layout of the packed 128-bit rank key: fields in rank-rule order, most significant first
+struct KeyField { int8_t kind; uint8_t bits; uint8_t shift; uint8_t hi; };   // hi: 1 = in key_hi
+// kinds
+enum { KF_TYPO, KF_PROX, KF_POS, KF_EXACT, KF_FIELD, KF_COMP_DESC, KF_COMP_ASC };
+
+struct SelJob {                      // one top-k selection (rank keys of a squery, or facet bins)
+    const uint64_t *key_hi, *key_lo;
+    uint32_t *cand[2];               // ping-pong candidate index buffers (capacity m_cap)
+    uint32_t *hist;                  // [MG_SEL_BINS]
+    uint32_t *ctl;                   // control words, see SEL_* below
+    const uint32_t *m_ptr;           // number of keys (device word)
+    uint32_t k;
+    uint32_t m_cap;
+    uint32_t *out_idx;               // [k] selected indices, sorted by (key, idx)
+    uint32_t *out_n;                 // number selected = min(k, m)
+    const uint64_t *mask;            // [2] varying bits (or ^ and): hi, lo ; NULL = all bits vary
+    uint32_t skip_ones;              // facet jobs: never select keys with key_hi == ~0 (zero counts)
+};
+// ctl words
+enum { SEL_NCAND, SEL_KREM, SEL_NWIN, SEL_DONE, SEL_TICKET, SEL_NEXT, SEL_BITPOS, SEL_PASS, SEL_WORDS = 16 };
+
+struct AggPart { double sum, mn, mx; unsigned long long cnt; };
+
+// Device-side descriptor of one (shard, query) pair.
+struct SqDev {
+    ShardDev sh;
+    // ---- formula ----
+    int32_t  num_terms, num_words;
+    int32_t  empty;                  // plan says: result is empty (filter_null)
+    uint32_t term_dense_off[MGPU_MAX_TERMS + 1];   // into blob (u32 dense row indices)
+    int32_t  term_row[MGPU_MAX_TERMS];             // scratch row index holding scattered sparse postings, or -1
+    uint64_t *rows;                  // scratch rows [nrows][Wp], zeroed per query
+    // ---- filter ----
+    int32_t  num_fops;
+    uint32_t fops_off;               // into blob: 4 u32 per op {op, a, _, _}; operand a: dense row (>=0) or ~scratch row
+    // ---- outputs of formula/compact ----
+    uint64_t *docid_map;             // [Wp]
+    uint32_t *blk_cnt;               // [nblk + 1] counts, then exclusive offsets
+    uint32_t nblk;
+    uint32_t *num_hits;              // device word
+    uint32_t *hits;                  // [N] ascending docids
+    // ---- rank ----
+    int32_t  do_rank;                // hits_per_page > 0 && num_words > 0
+    int32_t  rank_by;
+    uint32_t hash_off, hash_mask;    // wid table in blob: 2 u32 per slot {wid, val}; wid 0 = empty
+    uint16_t exact_present;
+    int32_t  nkf;
+    KeyField kf[8];
+    uint64_t *key_hi, *key_lo;       // [N]
+    uint64_t *key_andor;             // [4] and_hi, and_lo, or_hi, or_lo
+    uint32_t *ovf_cnt;               // overflow doc list counter
+    uint32_t *ovf_list;              // [N] hit indices whose position lists overflowed
+    // ---- doc processing (facets + aggs) ----
+    uint32_t hist_mask;              // bit f: histogram field f
+    uint32_t *hist[MGPU_MAX_FIELDS]; // [fa_nord[f]] zeroed per query
+    int32_t  num_aggs;
+    int32_t  agg_type[MGPU_MAX_AGGS];
+    int32_t  agg_field[MGPU_MAX_AGGS];
+    AggPart *agg_part;               // [nproc_blocks][num_aggs]
+    AggPart *agg_out;                // [num_aggs]
+    uint32_t nproc_blocks;
+    // facet selection keys
+    uint64_t *fkey_hi[MGPU_MAX_FIELDS], *fkey_lo[MGPU_MAX_FIELDS];
+    uint32_t *fnnz[MGPU_MAX_FIELDS];   // number of bins (device word, = fa_nord)
+    // ---- status ----
+    uint32_t *err;                   // device word, nonzero = MGPU_E_* (negated)
+};
+
+struct ScatterItem {                 // one chunk of a sorted docid list OR-ed into a scratch row
+    const uint32_t *src;
+    uint64_t *dst;
+    uint32_t n;
+    uint32_t pad;
+};

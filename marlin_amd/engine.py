@@ -1,0 +1,165 @@
+"""GPU execution of parsed queries and result assembly.
+
+`GpuEngine` owns one mgpu context (= one HIP stream) and the HBM mirrors of an index's shards
+on one device, and runs execute_squery for every (query, shard) pair of a batch in one set of
+launches (msq_execute_batch -> mgpu_execute).  `assemble` is the merge half of form_result
+(query.c:312-383) plus a dict rendering of the response fields the reference puts in JSON.
+There is no CPU fallback: if libmarlin_gpu.so or a GPU is missing, construction fails.
+"""
+import ctypes as C
+
+from . import ffi
+
+
+class GpuError(RuntimeError):
+    pass
+
+
+def assemble(index, pq, sqres):
+    """sqres: ctypes array of SqResult, one per shard.  Returns a dict shaped like the
+    reference's response (query.c:312-422) without the stored documents' bodies."""
+    lib = index.lib
+    res = ffi.Result()
+    lib.m_form_result(pq.q, sqres, index.num_shards, C.byref(res))
+    q = pq.q.contents
+    out = {"totalHits": res.total_hits, "numHits": res.num_hits, "page": q.page_num,
+           "fullScan": bool(res.full_scan), "hits": [], "facets": {}, "ranks": []}
+    for i in range(res.total_ranks):
+        r = res.ranks[i]
+        rec = {"docid": r.docid, "shard": r.shard_id, "typos": r.typos, "proximity": r.proximity,
+               "position": r.position, "exact": r.exact, "field": r.field, "compare": r.compare}
+        out["ranks"].append(rec)
+        if res.page_s <= i < res.page_e:
+            hit = {"_docid": r.docid, "_shard": r.shard_id}
+            docs = index.docs[r.shard_id] if index.docs else None
+            if docs:
+                hit.update(docs[r.docid - 1])
+            if pq.explain:
+                hit["_explain"] = {k: rec[k] for k in ("typos", "proximity", "position", "exact", "field")}
+            out["hits"].append(hit)
+    for f in range(res.num_facets):
+        if not q.cfg.facet_enabled[f] or f >= len(index.facets):
+            continue
+        lst = []
+        for x in range(res.fcount[f]):
+            fc = res.fc[f][x]
+            lst.append({"key": index.facet_string(fc.shard_id, fc.facet_id), "count": fc.count,
+                        "facet_id": fc.facet_id})
+        out["facets"][index.facets[f]] = lst
+    if res.num_aggs:
+        aggs = {}
+        for a in range(res.num_aggs):
+            ag = res.aggs[a]
+            name = pq.agg_names[a]
+            if ag.type == ffi.MA_MAX or ag.type == ffi.MA_MIN:
+                aggs[name] = {"value": ag.value}
+            elif ag.type == ffi.MA_AVG:
+                aggs[name] = {"value": (ag.sum / ag.count) if ag.count else float("nan"), "sum": ag.sum, "count": ag.count}
+            elif ag.type == ffi.MA_STATS:
+                aggs[name] = {"avg": (ag.sum / ag.count) if ag.count else float("nan"), "sum": ag.sum,
+                              "min": ag.min, "max": ag.max, "count": ag.count}
+            elif ag.type == ffi.MA_CARDINALITY:
+                aggs[name] = {"value": ag.card_n}
+        out["aggs"] = aggs
+    lib.m_result_free(C.byref(res))
+    return out
+
+
+def shard_results_to_py(index, pq, sqres):
+    """per-shard raw results (for stage-level parity tests)"""
+    out = []
+    q = pq.q.contents
+    for s in range(index.num_shards):
+        r = sqres[s]
+        d = {"num_hits": r.num_hits, "rank_count": r.rank_count,
+             "ranks": [(r.ranks[i].docid, r.ranks[i].typos, r.ranks[i].proximity, r.ranks[i].field,
+                        r.ranks[i].position, r.ranks[i].exact, r.ranks[i].compare) for i in range(r.rank_count)],
+             "facets": {}, "aggs": []}
+        for f in range(r.num_facets):
+            if q.cfg.facet_enabled[f]:
+                d["facets"][f] = [(r.fc[f][x].facet_id, r.fc[f][x].count) for x in range(r.rcount[f])]
+        for a in range(r.num_aggs):
+            ag = r.aggs[a]
+            d["aggs"].append({"type": ag.type, "value": ag.value, "sum": ag.sum, "min": ag.min, "max": ag.max,
+                              "count": ag.count, "card": [ag.card_ids[i] for i in range(ag.card_n)]})
+        if r.dbg_docid_map:
+            d["docid_map"] = [r.dbg_docid_map[i] for i in range(r.dbg_words)]
+        if r.dbg_all_ranks:
+            d["all_ranks"] = [(x.docid, x.typos, x.proximity, x.field, x.position, x.exact, x.compare)
+                              for x in (r.dbg_all_ranks[i] for i in range(r.num_hits))]
+        out.append(d)
+    return out
+
+
+class GpuEngine:
+    def __init__(self, index, device=0, scratch_bytes=0):
+        self.lib = lib = ffi.load()
+        self.index = index
+        self.device = device
+        if lib.mgpu_device_count() <= device:
+            raise GpuError("no HIP device %d visible (mgpu_device_count=%d)" % (device, lib.mgpu_device_count()))
+        self.ctx = C.c_void_p()
+        rc = lib.mgpu_ctx_create(device, scratch_bytes, C.byref(self.ctx))
+        if rc:
+            raise GpuError("mgpu_ctx_create: %d %s" % (rc, lib.mgpu_last_error().decode()))
+        self.mirrors = []
+        for s in index.shards:
+            m = C.c_void_p()
+            rc = lib.mmirror_create(s, device, C.byref(m))
+            if rc:
+                raise GpuError("mmirror_create: %d %s" % (rc, lib.mgpu_last_error().decode()))
+            self.mirrors.append(m)
+        self._marr = (C.c_void_p * len(self.mirrors))(*[m.value for m in self.mirrors])
+
+    def close(self):
+        for m in self.mirrors:
+            self.lib.mmirror_destroy(m)
+        self.mirrors = []
+        if self.ctx:
+            self.lib.mgpu_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def set_profiling(self, on):
+        self.lib.mgpu_ctx_set_profiling(self.ctx, 1 if on else 0)
+
+    def execute_raw(self, pqs, capture=0):
+        """returns a ctypes SqResult array of len(pqs) * num_shards (caller frees with free_raw)"""
+        ns = self.index.num_shards
+        nq = len(pqs)
+        qarr = (C.POINTER(ffi.Query) * nq)(*[p.q for p in pqs])
+        outs = (ffi.SqResult * (nq * ns))()
+        rc = self.lib.msq_execute_batch(self.ctx, self._marr, ns, qarr, nq, capture, outs)
+        if rc:
+            self.free_raw(outs)
+            raise GpuError("msq_execute_batch: %d %s" % (rc, self.lib.mgpu_last_error().decode()))
+        return outs
+
+    def free_raw(self, outs):
+        for i in range(len(outs)):
+            self.lib.m_sqresult_free(C.byref(outs[i]))
+
+    def search(self, pqs, capture=0):
+        """list of parsed queries -> list of assembled result dicts"""
+        single = not isinstance(pqs, (list, tuple))
+        if single:
+            pqs = [pqs]
+        ns = self.index.num_shards
+        outs = self.execute_raw(pqs, capture)
+        res = []
+        for i, pq in enumerate(pqs):
+            sub = (ffi.SqResult * ns).from_address(C.addressof(outs) + i * ns * C.sizeof(ffi.SqResult))
+            r = assemble(self.index, pq, sub)
+            if capture:
+                r["_shards"] = shard_results_to_py(self.index, pq, sub)
+            res.append(r)
+        self.free_raw(outs)
+        return res[0] if single else res
+
+    def timing(self):
+        tot = C.c_float()
+        st = (C.c_float * 8)()
+        self.lib.mgpu_last_timing(self.ctx, C.byref(tot), st)
+        by = (C.c_uint64 * 8)()
+        self.lib.mgpu_last_bytes(self.ctx, by)
+        return {"total_ms": tot.value,
+                "stages": {self.lib.mgpu_stage_name(i).decode(): {"ms": st[i], "bytes": by[i]} for i in range(8)}}

@@ -1,0 +1,174 @@
+"""ctypes bindings of the host library (libmarlin_host.so) and, through it, of the GPU C ABI.
+
+Python is plumbing here: tests, bench.py and the multi-GPU launcher drive the C entry points
+declared in marlin_amd/host/*.h and include/marlin_gpu.h.  The structures below mirror
+marlin_amd/host/mcommon.h field for field; sizes are verified against the library at import.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(_HERE, "lib")
+
+M_MAX_WORD_LEN = 127
+M_MAX_QWORDS = 16
+M_MAX_QTERMS = 32
+M_MAX_FIELDS = 32
+M_MAX_RULES = 10
+M_MAX_AGGS = 16
+
+# enums (mcommon.h)
+MR_TYPO, MR_PROX, MR_POS, MR_EXACT, MR_FIELD, MR_GEO, MR_DONE, MR_COMP, MR_COMP_ASC, MR_MAX = range(10)
+MF_AND, MF_OR, MF_NIN, MF_EQ, MF_NE, MF_GT, MF_GTE, MF_LT, MF_LTE, MF_RANGE, MF_ERROR = range(11)
+MT_STRING, MT_NUMBER, MT_BOOLEAN, MT_OTHER = range(4)
+MA_ROOT, MA_MAX, MA_MIN, MA_AVG, MA_STATS, MA_CARDINALITY, MA_ERROR = range(7)
+MPREFIX_LAST, MPREFIX_ALL, MPREFIX_NONE = range(3)
+MTYPO_OK, MTYPO_NONE = range(2)
+
+RULE_NAMES = {"typos": MR_TYPO, "proximity": MR_PROX, "position": MR_POS, "exact": MR_EXACT,
+              "field": MR_FIELD, "geo": MR_GEO}          # sort.c:11-18
+
+
+class DocRank(C.Structure):
+    _fields_ = [("compare", C.c_double), ("docid", C.c_uint32), ("distance", C.c_uint32),
+                ("position", C.c_uint16), ("proximity", C.c_uint16), ("typos", C.c_uint8),
+                ("exact", C.c_uint8), ("field", C.c_uint8), ("shard_id", C.c_uint8)]
+
+
+class FacetCount(C.Structure):
+    _fields_ = [("shard_id", C.c_uint8), ("facet_id", C.c_uint32), ("count", C.c_uint32)]
+
+
+class Word(C.Structure):
+    _fields_ = [("length", C.c_int), ("chars", C.c_uint32 * (M_MAX_WORD_LEN + 1))]
+
+
+class Term(C.Structure):
+    _fields_ = [("word", Word), ("prefix", C.c_uint8), ("typos", C.c_uint8)]
+
+
+class Filter(C.Structure):
+    pass
+
+
+Filter._fields_ = [("type", C.c_int), ("field_type", C.c_int), ("i_priority", C.c_int),
+                   ("f_priority", C.c_int), ("is_facet", C.c_int), ("facet_id", C.c_uint32),
+                   ("numval", C.c_double), ("numval2", C.c_double), ("numcmp1", C.c_int),
+                   ("numcmp2", C.c_int), ("num_children", C.c_int),
+                   ("children", C.POINTER(C.POINTER(Filter)))]
+
+
+class Agg(C.Structure):
+    _fields_ = [("type", C.c_int), ("field", C.c_int), ("value", C.c_double), ("sum", C.c_double),
+                ("min", C.c_double), ("max", C.c_double), ("count", C.c_int),
+                ("card_ids", C.POINTER(C.c_uint32)), ("card_n", C.c_uint32)]
+
+
+class QueryCfg(C.Structure):
+    _fields_ = [("prefix", C.c_int), ("typos", C.c_int), ("hits_per_page", C.c_uint16),
+                ("max_hits", C.c_uint16), ("max_facet_results", C.c_uint16), ("num_rules", C.c_int),
+                ("rank_by", C.c_int), ("rank_sort", C.c_bool), ("rank_asc", C.c_bool),
+                ("full_scan", C.c_bool), ("full_scan_threshold", C.c_uint32),
+                ("rank_algo", C.c_int * M_MAX_RULES), ("facet_enabled", C.c_int * M_MAX_FIELDS)]
+
+
+class Query(C.Structure):
+    _fields_ = [("text", C.c_char_p), ("num_words", C.c_int), ("words", Word * M_MAX_QWORDS),
+                ("num_terms", C.c_int), ("terms", Term * M_MAX_QTERMS),
+                ("filter", C.POINTER(Filter)), ("num_aggs", C.c_int), ("aggs", Agg * M_MAX_AGGS),
+                ("cfg", QueryCfg), ("page_num", C.c_uint16), ("rank_rule", C.c_int * M_MAX_RULES)]
+
+
+class SqResult(C.Structure):
+    _fields_ = [("num_hits", C.c_uint32), ("rank_count", C.c_int), ("ranks", C.POINTER(DocRank)),
+                ("num_facets", C.c_int), ("rcount", C.c_int * M_MAX_FIELDS),
+                ("fc", C.POINTER(FacetCount) * M_MAX_FIELDS), ("num_aggs", C.c_int),
+                ("aggs", Agg * M_MAX_AGGS), ("fast_rank", C.c_bool),
+                ("dbg_docid_map", C.POINTER(C.c_uint64)), ("dbg_words", C.c_uint32),
+                ("dbg_all_ranks", C.POINTER(DocRank))]
+
+
+class Result(C.Structure):
+    _fields_ = [("total_hits", C.c_int), ("num_hits", C.c_int), ("page_s", C.c_int), ("page_e", C.c_int),
+                ("total_ranks", C.c_int), ("ranks", C.POINTER(DocRank)), ("num_facets", C.c_int),
+                ("fcount", C.c_int * M_MAX_FIELDS), ("fc", C.POINTER(FacetCount) * M_MAX_FIELDS),
+                ("num_aggs", C.c_int), ("aggs", Agg * M_MAX_AGGS), ("full_scan", C.c_bool)]
+
+
+class ShardStruct(C.Structure):
+    """leading fields of mshard_t that Python reads directly"""
+    _fields_ = [("max_docid", C.c_uint32), ("num_strings", C.c_int), ("num_numbers", C.c_int),
+                ("num_bools", C.c_int), ("num_facets", C.c_int)]
+
+
+_lib = None
+
+
+def load():
+    """Loads libmarlin_host.so (which links libmarlin_gpu.so).  Fails loudly when not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = os.path.join(LIB_DIR, "libmarlin_host.so")
+    if not os.path.exists(path):
+        raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "or `make` in the repo root" % path)
+    # the GPU library first, so the dependency resolves without an rpath lookup surprise
+    C.CDLL(os.path.join(LIB_DIR, "libmarlin_gpu.so"), mode=C.RTLD_GLOBAL)
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    vp, ci, cu, cd = C.c_void_p, C.c_int, C.c_uint32, C.c_double
+    sigs = {
+        "m_sizeof": (C.c_size_t, [ci]),
+        "msb_new": (vp, [ci, ci, ci, ci]),
+        "msb_begin_doc": (cu, [vp]),
+        "msb_add_string": (None, [vp, ci, C.c_char_p]),
+        "msb_add_number": (None, [vp, ci, cd, ci]),
+        "msb_add_facet_str": (None, [vp, ci, C.c_char_p]),
+        "msb_add_facet_num": (None, [vp, ci, cd]),
+        "msb_add_bool": (None, [vp, ci, ci]),
+        "msb_end_doc": (None, [vp]),
+        "msb_finalize": (vp, [vp]),
+        "mshard_free": (None, [vp]),
+        "mshard_lookup_facet": (C.c_char_p, [vp, cu]),
+        "m_facet_id": (cu, [C.c_char_p, C.c_size_t]),
+        "m_farmhash32_mk": (cu, [C.c_char_p, C.c_size_t]),
+        "msynth_datagen": (vp, [cu, C.c_uint64, C.POINTER(C.c_char_p), ci, C.POINTER(cu)]),
+        "msynth_zipf": (vp, [C.c_uint64, cu, cu, C.c_uint64, ci, ci]),
+        "msynth_zipf_word": (ci, [cu, C.c_uint64, cu, C.c_char_p]),
+        "msynth_route": (ci, [C.c_uint64, ci]),
+        "mq_new": (C.POINTER(Query), [ci]),
+        "mq_free": (None, [C.POINTER(Query)]),
+        "mq_set_text": (ci, [C.POINTER(Query), C.c_char_p]),
+        "mq_build_rank_rule": (None, [C.POINTER(Query)]),
+        "mf_new": (C.POINTER(Filter), [ci]),
+        "mf_add_child": (None, [C.POINTER(Filter), C.POINTER(Filter)]),
+        "mf_free": (None, [C.POINTER(Filter)]),
+        "mq_add_agg": (ci, [C.POINTER(Query), ci, ci]),
+        "m_form_result": (None, [C.POINTER(Query), C.POINTER(SqResult), ci, C.POINTER(Result)]),
+        "m_result_free": (None, [C.POINTER(Result)]),
+        "m_sqresult_free": (None, [C.POINTER(SqResult)]),
+        "mmirror_create": (ci, [vp, ci, C.POINTER(vp)]),
+        "mmirror_destroy": (None, [vp]),
+        "msq_execute_batch": (ci, [vp, C.POINTER(vp), ci, C.POINTER(C.POINTER(Query)), ci, ci, C.POINTER(SqResult)]),
+        # GPU C ABI (include/marlin_gpu.h), reached through the same process image
+        "mgpu_last_error": (C.c_char_p, []),
+        "mgpu_device_count": (ci, []),
+        "mgpu_ctx_create": (ci, [ci, C.c_uint64, C.POINTER(vp)]),
+        "mgpu_ctx_destroy": (None, [vp]),
+        "mgpu_ctx_set_profiling": (None, [vp, ci]),
+        "mgpu_last_timing": (ci, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+        "mgpu_last_bytes": (ci, [vp, C.POINTER(C.c_uint64)]),
+        "mgpu_stage_name": (C.c_char_p, [ci]),
+        "mgpu_shard_bytes": (C.c_uint64, [vp]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    expect = [DocRank, FacetCount, Agg, QueryCfg, Query, SqResult, Result, Filter, Word, Term]
+    for i, st in enumerate(expect):
+        if lib.m_sizeof(i) != C.sizeof(st):
+            raise RuntimeError("ctypes mirror of %s is %d bytes, library says %d"
+                               % (st.__name__, C.sizeof(st), lib.m_sizeof(i)))
+    _lib = lib
+    return lib

@@ -1,0 +1,372 @@
+/* mplan.c -- see mplan.h */
+#include "mplan.h"
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+#include <stdio.h>
+
+/* ------------------------------------------------------------------ mirror export */
+int mmirror_create(const mshard_t *s, int device, mmirror_t **out) {
+    mmirror_t *m = calloc(1, sizeof(*m));
+    m->s = s; m->device = device;
+    m->W = s->word_count; m->T = s->tword_count;
+    uint32_t pid = 1 + m->W + m->T;
+    for (int f = 0; f < s->num_facets; f++) { m->fbase[f] = pid; pid += s->nfid[f]; }
+    m->bbase = pid; pid += 2u * (uint32_t)s->num_bools;
+    m->num_postings = pid;
+
+    uint64_t total = s->max_docid;
+    total += s->wp_off[m->W + 1] + s->tp_off[m->T + 1];
+    for (int f = 0; f < s->num_facets; f++) total += s->fp_off[f][s->nfid[f]];
+    for (int i = 0; i < s->num_bools; i++) total += s->bp_n[i][0] + s->bp_n[i][1];
+    uint64_t *off = malloc(((size_t)pid + 1) * sizeof(uint64_t));
+    uint32_t *doc = malloc((total ? total : 1) * sizeof(uint32_t));
+    uint64_t at = 0;
+    uint32_t p = 0;
+    off[p++] = 0;                                           /* pid 0: every used docid (shard.c:51-53) */
+    for (uint32_t d = 1; d <= s->max_docid; d++) doc[at++] = d;
+    for (uint32_t w = 1; w <= m->W; w++) {
+        off[p++] = at;
+        uint64_t n = s->wp_off[w + 1] - s->wp_off[w];
+        memcpy(doc + at, s->wp_doc + s->wp_off[w], n * sizeof(uint32_t)); at += n;
+    }
+    for (uint32_t t = 1; t <= m->T; t++) {
+        off[p++] = at;
+        uint64_t n = s->tp_off[t + 1] - s->tp_off[t];
+        memcpy(doc + at, s->tp_doc + s->tp_off[t], n * sizeof(uint32_t)); at += n;
+    }
+    for (int f = 0; f < s->num_facets; f++) {
+        for (uint32_t k = 0; k < s->nfid[f]; k++) {
+            off[p++] = at;
+            uint64_t n = s->fp_off[f][k + 1] - s->fp_off[f][k];
+            memcpy(doc + at, s->fp_doc[f] + s->fp_off[f][k], n * sizeof(uint32_t)); at += n;
+        }
+    }
+    for (int i = 0; i < s->num_bools; i++) {
+        for (int v = 0; v < 2; v++) {
+            off[p++] = at;
+            if (s->bp_n[i][v]) memcpy(doc + at, s->bp_doc[i][v], s->bp_n[i][v] * sizeof(uint32_t));
+            at += s->bp_n[i][v];
+        }
+    }
+    off[p] = at;
+
+    mgpu_shard_desc_t d;
+    memset(&d, 0, sizeof(d));
+    d.max_docid = s->max_docid;
+    d.num_numbers = s->num_numbers; d.num_facets = s->num_facets;
+    d.num_postings = pid; d.post_off = off; d.post_doc = doc;
+    d.dd_off = s->dd_off; d.dd = s->dd;
+    for (int i = 0; i < s->num_numbers; i++) { d.np_n[i] = s->np_n[i]; d.np_doc[i] = s->np_doc[i]; }
+    int rc = mgpu_shard_create(device, &d, &m->g);
+    free(off); free(doc);
+    if (rc) { free(m); return rc; }
+    *out = m;
+    return 0;
+}
+
+void mmirror_destroy(mmirror_t *m) {
+    if (!m) return;
+    mgpu_shard_destroy(m->g);
+    free(m);
+}
+
+/* ------------------------------------------------------------------ plan */
+void mplan_free(mplan_t *pl) {
+    for (int t = 0; t < MGPU_MAX_TERMS; t++) free(pl->term_post[t]);
+    free(pl->wids); free(pl->fops);
+    memset(pl, 0, sizeof(*pl));
+}
+
+static void fop_push(mplan_t *pl, int op, int a, uint64_t lo, uint64_t hi) {
+    if (pl->p.num_fops == pl->fops_cap) {
+        pl->fops_cap = pl->fops_cap ? pl->fops_cap * 2 : 16;
+        pl->fops = realloc(pl->fops, sizeof(mgpu_fop_t) * (size_t)pl->fops_cap);
+    }
+    mgpu_fop_t *f = &pl->fops[pl->p.num_fops++];
+    f->op = op; f->a = a; f->lo = lo; f->hi = hi;
+}
+
+static int check_op(int f, double a, double b) {            /* check_double_oper, filter_apply.c:127-144 */
+    switch (f) {
+        case MF_LT: return a < b;
+        case MF_LTE: return a <= b;
+        case MF_GT: return a > b;
+        case MF_GTE: return a >= b;
+        default: return 0;
+    }
+}
+
+/* first index k with val[k] <= x (values descending) */
+static uint64_t lb_desc(const double *val, uint64_t n, double x) {
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) { uint64_t mid = (lo + hi) / 2; if (val[mid] > x) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+/* Lowers one filter node (post order, filter_apply.c:207-213).  Returns 1 when the node
+ * leaves a bitmap on the stack, 0 when the reference would leave fr_bmap NULL. */
+static int lower_filter(const mmirror_t *m, const m_filter_t *f, mplan_t *pl) {
+    const mshard_t *s = m->s;
+    switch (f->type) {
+        case MF_EQ: case MF_NE: {
+            int have = 0;
+            if (f->field_type == MT_NUMBER) {                        /* num_eq_filter */
+                int fi = f->i_priority;
+                if (fi >= 0 && fi < s->num_numbers) {
+                    uint64_t n = s->np_n[fi];
+                    uint64_t a = lb_desc(s->np_val[fi], n, f->numval), b = a;
+                    while (b < n && s->np_val[fi][b] == f->numval) b++;
+                    fop_push(pl, MGPU_F_PUSH_NUMRANGE, fi, a, b);
+                } else fop_push(pl, MGPU_F_PUSH_EMPTY, 0, 0, 0);
+                have = 1;
+            } else if (f->field_type == MT_STRING) {                 /* str_eq_filter */
+                if (f->is_facet) {
+                    int ff = f->f_priority;
+                    int found = 0;
+                    if (ff >= 0 && ff < s->num_facets) {
+                        uint32_t lo = 0, hi = s->nfid[ff];
+                        while (lo < hi) { uint32_t mid = (lo + hi) / 2; if (s->fid[ff][mid] < f->facet_id) lo = mid + 1; else hi = mid; }
+                        if (lo < s->nfid[ff] && s->fid[ff][lo] == f->facet_id) {
+                            fop_push(pl, MGPU_F_PUSH_POSTING, (int)(m->fbase[ff] + lo), 0, 0);
+                            found = 1;
+                        }
+                    }
+                    if (!found) fop_push(pl, MGPU_F_PUSH_EMPTY, 0, 0, 0);
+                    have = 1;
+                }
+            } else if (f->field_type == MT_BOOLEAN) {                /* bool_eq_filter */
+                int bi = f->i_priority;
+                if (bi >= 0 && bi < s->num_bools)
+                    fop_push(pl, MGPU_F_PUSH_POSTING, (int)(m->bbase + 2u * (uint32_t)bi + (f->numval != 0.0 ? 1u : 0u)), 0, 0);
+                else fop_push(pl, MGPU_F_PUSH_EMPTY, 0, 0, 0);
+                have = 1;
+            }
+            if (f->type == MF_NE) {                                  /* ne_filter */
+                if (!have) fop_push(pl, MGPU_F_PUSH_EMPTY, 0, 0, 0);
+                fop_push(pl, MGPU_F_DOCS_ANDNOT, 0, 0, 0);
+                have = 1;
+            }
+            return have;
+        }
+        case MF_OR: case MF_NIN: case MF_AND: {
+            int cnt = 0;
+            for (int i = 0; i < f->num_children; i++) {
+                if (lower_filter(m, f->children[i], pl)) {
+                    cnt++;
+                    if (cnt > 1) fop_push(pl, f->type == MF_AND ? MGPU_F_AND : MGPU_F_OR, 0, 0, 0);
+                }
+            }
+            if (cnt == 0) fop_push(pl, MGPU_F_PUSH_EMPTY, 0, 0, 0);  /* oper_and / oper_or of nothing */
+            if (f->type == MF_NIN) fop_push(pl, MGPU_F_DOCS_ANDNOT, 0, 0, 0);
+            return 1;
+        }
+        case MF_GT: case MF_GTE: case MF_LT: case MF_LTE: {          /* num_filter */
+            /* children of a leaf are evaluated first and ignored (none in practice) */
+            if (f->field_type != MT_NUMBER) return 0;
+            int fi = f->i_priority;
+            if (fi < 0 || fi >= s->num_numbers) { fop_push(pl, MGPU_F_PUSH_EMPTY, 0, 0, 0); return 1; }
+            uint64_t n = s->np_n[fi];
+            const double *val = s->np_val[fi];
+            if (f->type == MF_GT || f->type == MF_GTE) {
+                uint64_t lo = 0, hi = n;                             /* first index failing the test */
+                while (lo < hi) { uint64_t mid = (lo + hi) / 2; if (check_op(f->type, val[mid], f->numval)) lo = mid + 1; else hi = mid; }
+                fop_push(pl, MGPU_F_PUSH_NUMRANGE, fi, 0, lo);
+            } else {
+                uint64_t lo = 0, hi = n;                             /* first index passing the test */
+                while (lo < hi) { uint64_t mid = (lo + hi) / 2; if (check_op(f->type, val[mid], f->numval)) hi = mid; else lo = mid + 1; }
+                fop_push(pl, MGPU_F_PUSH_NUMRANGE, fi, lo, n);
+            }
+            return 1;
+        }
+        case MF_RANGE: {                                             /* num_range_filter */
+            if (f->field_type != MT_NUMBER) return 0;
+            int fi = f->i_priority;
+            if (fi < 0 || fi >= s->num_numbers) { fop_push(pl, MGPU_F_PUSH_EMPTY, 0, 0, 0); return 1; }
+            uint64_t n = s->np_n[fi];
+            const double *val = s->np_val[fi];
+            /* the cursor starts at the first key <= numval2 (MDB_SET_RANGE on a descending tree);
+             * keys failing the upper test are skipped, the first key failing the lower test ends
+             * the walk (filter_apply.c:182-191).  Keys descend, so both tests are monotone. */
+            uint64_t a = lb_desc(val, n, f->numval2), b;
+            if (f->numcmp2 == MF_LT) {
+                uint64_t lo = a, hi = n;
+                while (lo < hi) { uint64_t mid = (lo + hi) / 2; if (val[mid] < f->numval2) hi = mid; else lo = mid + 1; }
+                a = lo;
+            } else if (f->numcmp2 != MF_LTE) {
+                a = n;
+            }
+            {
+                uint64_t lo = a, hi = n;
+                while (lo < hi) { uint64_t mid = (lo + hi) / 2; if (check_op(f->numcmp1, val[mid], f->numval)) lo = mid + 1; else hi = mid; }
+                b = lo;
+            }
+            fop_push(pl, MGPU_F_PUSH_NUMRANGE, fi, a, b);
+            return 1;
+        }
+        default:
+            return 0;
+    }
+}
+
+int mplan_build(const mmirror_t *m, const m_query_t *q, int capture, mplan_t *pl) {
+    memset(pl, 0, sizeof(*pl));
+    const mshard_t *s = m->s;
+    mgpu_plan_t *p = &pl->p;
+    p->num_terms = q->num_terms; p->num_words = q->num_words;
+    if (q->num_terms > MGPU_MAX_TERMS || q->num_words > MGPU_MAX_WORDS) return MGPU_E_LIMIT;
+
+    m_termresult_t tr[M_MAX_QTERMS];
+    m_u32map_t all; m_u32map_init(&all);
+    /* lookup_terms + process_termresult (squery.c:72-118, 144-167) */
+    for (int t = 0; t < q->num_terms; t++) {
+        mdict_lookup_term(s->dict, &q->terms[t], &tr[t]);
+        const uint32_t *docs;
+        if (tr[t].twid == 0 && tr[t].wordids.n == 0) { p->term_npost[t] = 0; continue; }
+        if (tr[t].twid) {
+            uint64_t n = mshard_twid_posting(s, tr[t].twid, &docs);
+            pl->term_post[t] = malloc(sizeof(uint32_t));
+            if (n) {
+                pl->term_post[t][0] = m->W + tr[t].twid;
+                p->term_npost[t] = 1;
+                const uint32_t *wids;
+                uint64_t nw = mshard_twid_wids(s, tr[t].twid, &wids);
+                for (uint64_t i = 0; i < nw; i++) { m_u32map_set(&tr[t].wordids, wids[i], 0); m_u32map_set(&all, wids[i], 0); }
+            }
+            continue;
+        }
+        pl->term_post[t] = malloc(sizeof(uint32_t) * (tr[t].wordids.n ? tr[t].wordids.n : 1));
+        uint32_t np = 0;
+        for (uint32_t k = 0; k < tr[t].wordids.cap; k++) {
+            uint32_t wid = tr[t].wordids.keys[k];
+            if (!wid) continue;
+            if (!mshard_wid_posting(s, wid, &docs)) continue;
+            m_u32map_set(&all, wid, tr[t].wordids.vals[k]);
+            pl->term_post[t][np++] = wid;
+        }
+        p->term_npost[t] = np;
+    }
+    for (int t = 0; t < q->num_terms; t++) p->term_post[t] = pl->term_post[t];
+
+    /* exact wids (squery.c:159-166) */
+    uint32_t exact_wid[M_MAX_QWORDS];
+    for (int i = 0; i < q->num_words; i++) {
+        const uint32_t *docs;
+        uint32_t wid = mdict_lookup_exact(s->dict, &q->words[i]);
+        exact_wid[i] = 0;
+        if (wid && mshard_wid_posting(s, wid, &docs)) { exact_wid[i] = wid; p->exact_present |= (uint16_t)(1u << i); }
+    }
+    /* wid table: all_wordids distance, first matching term, exact bits */
+    {
+        uint32_t cap = all.n + (uint32_t)q->num_words + 1;
+        pl->wids = malloc(sizeof(mgpu_wid_entry_t) * cap);
+        uint32_t nw = 0;
+        for (uint32_t k = 0; k < all.cap; k++) {
+            uint32_t wid = all.keys[k];
+            if (!wid) continue;
+            mgpu_wid_entry_t *e = &pl->wids[nw++];
+            e->wid = wid; e->dist = (uint8_t)all.vals[k]; e->mterm = 0xFF; e->exact_mask = 0;
+            for (int t = 0; t < q->num_terms; t++)
+                if (m_u32map_get(&tr[t].wordids, wid, 0xFF) != 0xFF) { e->mterm = (uint8_t)t; break; }
+            for (int i = 0; i < q->num_words; i++) if (exact_wid[i] == wid) e->exact_mask |= (uint16_t)(1u << i);
+        }
+        for (int i = 0; i < q->num_words; i++) {
+            if (!exact_wid[i] || m_u32map_get(&all, exact_wid[i], -1) >= 0) continue;
+            int dup = 0;
+            for (uint32_t k = all.n; k < nw; k++) if (pl->wids[k].wid == exact_wid[i]) { pl->wids[k].exact_mask |= (uint16_t)(1u << i); dup = 1; }
+            if (dup) continue;
+            mgpu_wid_entry_t *e = &pl->wids[nw++];
+            e->wid = exact_wid[i]; e->dist = 0xFF; e->mterm = 0xFF; e->exact_mask = (uint16_t)(1u << i);
+        }
+        p->num_wids = nw; p->wids = pl->wids;
+    }
+    for (int t = 0; t < q->num_terms; t++) m_termresult_free(&tr[t]);
+    m_u32map_free(&all);
+
+    /* filter */
+    if (q->filter) {
+        p->has_filter = 1;
+        p->filter_null = lower_filter(m, q->filter, pl) ? 0 : 1;
+        p->fops = pl->fops;
+    }
+    /* config */
+    p->hits_per_page = q->cfg.hits_per_page; p->page_num = q->page_num;
+    p->max_facet_results = q->cfg.max_facet_results;
+    for (int f = 0; f < s->num_facets && f < 32; f++) if (q->cfg.facet_enabled[f]) p->facet_enabled |= 1u << f;
+    p->rank_by = q->cfg.rank_by; p->rank_asc = q->cfg.rank_asc;
+    for (int i = 0; i < MGPU_MAX_RULES; i++) p->rules[i] = q->rank_rule[i];
+    p->num_aggs = q->num_aggs;
+    for (int a = 0; a < q->num_aggs; a++) { p->agg_type[a] = q->aggs[a].type; p->agg_field[a] = q->aggs[a].field; }
+    p->capture = capture;
+    return 0;
+}
+
+/* ------------------------------------------------------------------ execution */
+int msq_execute_batch(mgpu_ctx_t *ctx, mmirror_t *const *mirrors, int num_shards,
+                      const m_query_t *const *queries, int nq, int capture, m_sqresult_t *outs) {
+    int n = nq * num_shards;
+    mplan_t *plans = calloc((size_t)n, sizeof(mplan_t));
+    mgpu_plan_t *gp = calloc((size_t)n, sizeof(mgpu_plan_t));
+    mgpu_shard_t **gs = calloc((size_t)n, sizeof(mgpu_shard_t *));
+    mgpu_sqout_t *go = calloc((size_t)n, sizeof(mgpu_sqout_t));
+    int rc = 0;
+    for (int qi = 0; qi < nq && !rc; qi++) {
+        for (int sidx = 0; sidx < num_shards && !rc; sidx++) {
+            int i = qi * num_shards + sidx;
+            rc = mplan_build(mirrors[sidx], queries[qi], capture, &plans[i]);
+            gp[i] = plans[i].p;
+            gs[i] = mirrors[sidx]->g;
+        }
+    }
+    if (!rc) rc = mgpu_execute(ctx, gs, gp, n, go);
+    for (int i = 0; i < n; i++) {
+        const m_query_t *q = queries[i / num_shards];
+        int sidx = i % num_shards;
+        m_sqresult_t *o = &outs[i];
+        memset(o, 0, sizeof(*o));
+        if (rc) continue;
+        mgpu_sqout_t *g = &go[i];
+        if (g->status) { rc = g->status; continue; }
+        /* perform_ranking would have taken the sampled fast-rank path (docrank.c:571): not built yet */
+        if (!q->cfg.full_scan && g->num_hits > q->cfg.full_scan_threshold && q->cfg.rank_by >= 0) { rc = MGPU_E_UNSUPPORTED; continue; }
+        o->num_hits = g->num_hits;
+        o->rank_count = g->rank_count;
+        o->ranks = (m_docrank_t *)g->ranks; g->ranks = NULL;        /* identical 24-byte layout */
+        for (int j = 0; j < o->rank_count; j++) o->ranks[j].shard_id = 0;
+        o->num_facets = mirrors[sidx]->s->num_facets;
+        for (int f = 0; f < o->num_facets; f++) {
+            if (!q->cfg.facet_enabled[f]) continue;
+            int rcnt = g->rcount[f];
+            o->rcount[f] = rcnt;
+            o->fc[f] = calloc((size_t)(rcnt ? rcnt : 1), sizeof(m_facet_count_t));
+            for (int x = 0; x < rcnt; x++) {
+                o->fc[f][x].facet_id = g->fc[f][x].facet_id; o->fc[f][x].count = g->fc[f][x].count;
+                o->fc[f][x].shard_id = (uint8_t)sidx;
+            }
+        }
+        o->num_aggs = q->num_aggs;
+        for (int a = 0; a < q->num_aggs; a++) {
+            m_agg_t *ag = &o->aggs[a];
+            *ag = q->aggs[a]; ag->card_ids = NULL; ag->card_n = 0;
+            const mgpu_agg_out_t *ga = &g->aggs[a];
+            switch (ag->type) {
+                case MA_MAX: if (ga->max > ag->value) ag->value = ga->max; break;
+                case MA_MIN: if (ga->min < ag->value) ag->value = ga->min; break;
+                case MA_AVG: ag->sum += ga->sum; ag->count += (int)ga->count; break;
+                case MA_STATS:
+                    ag->sum += ga->sum; ag->count += (int)ga->count;
+                    if (ga->min < ag->min) ag->min = ga->min;
+                    if (ga->max > ag->max) ag->max = ga->max;
+                    break;
+                case MA_CARDINALITY: ag->card_ids = ga->card_ids; ag->card_n = ga->card_n; g->aggs[a].card_ids = NULL; break;
+                default: break;
+            }
+        }
+        o->fast_rank = false;
+        o->dbg_docid_map = g->dbg_docid_map; o->dbg_words = g->dbg_words; g->dbg_docid_map = NULL;
+        o->dbg_all_ranks = (m_docrank_t *)g->dbg_all_ranks; g->dbg_all_ranks = NULL;
+    }
+    for (int i = 0; i < n; i++) { mgpu_sqout_free(&go[i]); mplan_free(&plans[i]); }
+    free(plans); free(gp); free(gs); free(go);
+    return rc;
+}

@@ -1,0 +1,59 @@
+/* mplan.h -- host side of the GPU shard query: mirror export and plan lowering.
+ *
+ * This is the part of execute_squery that stays on the CPU (squery.c:144-167 lookup_terms:
+ * trie lookups, twid -> wid expansion, wid -> distance maps; filter-tree leaves resolved to
+ * posting ids / key ranges) and hands a flat mgpu_plan_t to libmarlin_gpu.so.  It never
+ * touches the oracle; if the GPU library reports an error the error is returned.
+ */
+#ifndef MARLIN_AMD_MPLAN_H
+#define MARLIN_AMD_MPLAN_H
+
+#include "mcommon.h"
+#include "mshard.h"
+#include "mquery.h"
+#include "marlin_gpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* one shard's HBM mirror plus the posting-id scheme used to address it */
+typedef struct mmirror {
+    const mshard_t *s;
+    mgpu_shard_t   *g;
+    int       device;
+    uint32_t  W, T;                      /* word_count, tword_count */
+    uint32_t  fbase[M_MAX_FIELDS];       /* pid of field f's first facet posting */
+    uint32_t  bbase;                     /* pid of bool field 0 / false */
+    uint32_t  num_postings;
+} mmirror_t;
+
+/* pid 0 = all docs, 1..W = wid2bmap, W+1..W+T = twid2bmap, then facetid2bmap, then boolid2bmap */
+int  mmirror_create(const mshard_t *s, int device, mmirror_t **out);
+void mmirror_destroy(mmirror_t *m);
+
+typedef struct mplan {
+    mgpu_plan_t p;
+    /* owned storage behind the pointers in p */
+    uint32_t *term_post[MGPU_MAX_TERMS];
+    mgpu_wid_entry_t *wids;
+    mgpu_fop_t *fops;
+    int fops_cap;
+} mplan_t;
+
+/* lookup_terms + process_termresult + filter leaf resolution for one shard.
+ * returns 0, or MGPU_E_UNSUPPORTED when the query would take the fast-rank path
+ * (docrank.c:571) -- decided after execution from num_hits, see msq_execute. */
+int  mplan_build(const mmirror_t *m, const m_query_t *q, int capture, mplan_t *out);
+void mplan_free(mplan_t *pl);
+
+/* execute_squery for nq queries x num_shards shards in one GPU batch.
+ * mirrors[s] for s < num_shards must live on ctx's device.
+ * outs[qi * num_shards + s] receives shard s's result of query qi. */
+int  msq_execute_batch(mgpu_ctx_t *ctx, mmirror_t *const *mirrors, int num_shards,
+                       const m_query_t *const *queries, int nq, int capture, m_sqresult_t *outs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,351 @@
+/* mquery.c -- see mquery.h */
+#include "mquery.h"
+#include "mshard.h"
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+
+void m_sqresult_free(m_sqresult_t *r) {
+    if (!r) return;
+    free(r->ranks);
+    for (int f = 0; f < M_MAX_FIELDS; f++) free(r->fc[f]);
+    for (int i = 0; i < r->num_aggs; i++) free(r->aggs[i].card_ids);
+    free(r->dbg_docid_map);
+    free(r->dbg_all_ranks);
+    memset(r, 0, sizeof(*r));
+}
+
+/* query_config_new (index.c:1365-1378) + set_default_facets (index.c:74-78) */
+m_query_t *mq_new(int num_facets) {
+    m_query_t *q = calloc(1, sizeof(*q));
+    q->cfg.hits_per_page = 20;            /* DEF_HITS_PER_PAGE, index.h:19-24 */
+    q->cfg.max_facet_results = 10;
+    q->cfg.full_scan_threshold = 25000;
+    q->cfg.max_hits = 500;
+    q->cfg.rank_by = -1;
+    q->cfg.rank_sort = false;
+    q->cfg.rank_asc = false;
+    q->cfg.num_rules = 5;                 /* default_rule, sort.c:8-9 */
+    q->cfg.rank_algo[0] = MR_TYPO; q->cfg.rank_algo[1] = MR_PROX; q->cfg.rank_algo[2] = MR_FIELD;
+    q->cfg.rank_algo[3] = MR_POS;  q->cfg.rank_algo[4] = MR_EXACT;
+    for (int i = 0; i < num_facets && i < M_MAX_FIELDS; i++) q->cfg.facet_enabled[i] = 1;
+    q->page_num = 1;
+    mq_build_rank_rule(q);
+    return q;
+}
+
+void mf_free(m_filter_t *f) {
+    if (!f) return;
+    for (int i = 0; i < f->num_children; i++) mf_free(f->children[i]);
+    free(f->children);
+    free(f);
+}
+
+void mq_free(m_query_t *q) {
+    if (!q) return;
+    free(q->text);
+    mf_free(q->filter);
+    for (int i = 0; i < q->num_aggs; i++) free(q->aggs[i].card_ids);
+    free(q);
+}
+
+m_filter_t *mf_new(int type) {
+    m_filter_t *f = calloc(1, sizeof(*f));
+    f->type = type;
+    return f;
+}
+
+void mf_add_child(m_filter_t *p, m_filter_t *c) {
+    p->children = realloc(p->children, sizeof(m_filter_t *) * (size_t)(p->num_children + 1));
+    p->children[p->num_children++] = c;
+}
+
+int mq_add_agg(m_query_t *q, int type, int field) {
+    if (q->num_aggs >= M_MAX_AGGS) return -1;
+    m_agg_t *a = &q->aggs[q->num_aggs++];
+    memset(a, 0, sizeof(*a));
+    a->type = type; a->field = field;
+    /* initial states of parse_*_agg (metric-aggs.c:191-218, 312-338, 373-399) */
+    if (type == MA_MAX) a->value = -DBL_MAX;
+    if (type == MA_MIN) a->value = DBL_MAX;
+    if (type == MA_STATS) { a->min = DBL_MAX; a->max = -DBL_MAX; }
+    return 0;
+}
+
+/* index.c:1134-1148 */
+void mq_build_rank_rule(m_query_t *q) {
+    int rcount = 0;
+    if (q->cfg.rank_by >= 0) {
+        if (q->cfg.rank_sort) {
+            q->rank_rule[0] = q->cfg.rank_asc ? MR_COMP_ASC : MR_COMP;
+            q->rank_rule[q->cfg.num_rules + 1] = MR_DONE;
+            rcount++;
+        } else {
+            q->rank_rule[q->cfg.num_rules] = q->cfg.rank_asc ? MR_COMP_ASC : MR_COMP;
+            q->rank_rule[q->cfg.num_rules + 1] = MR_DONE;
+        }
+    } else {
+        q->rank_rule[q->cfg.num_rules] = MR_DONE;
+    }
+    memcpy(&q->rank_rule[rcount], q->cfg.rank_algo, (size_t)q->cfg.num_rules * sizeof(int));
+}
+
+static void word_cb(const chr_t *chars, int length, int position, void *data) {
+    (void)position;
+    m_query_t *q = data;                                   /* query_string_word_cb, index.c:909-917 */
+    if (q->num_words >= M_MAX_QWORDS) { q->num_words++; return; }
+    m_word_t *w = &q->words[q->num_words++];
+    w->length = length;
+    memcpy(w->chars, chars, sizeof(chr_t) * (size_t)length);
+}
+
+static inline void word_cat(m_word_t *dst, const m_word_t *src) {     /* wordcat, word.c */
+    int n = src->length;
+    if (dst->length + n > M_MAX_WORD_LEN) n = M_MAX_WORD_LEN - dst->length;
+    memcpy(dst->chars + dst->length, src->chars, sizeof(chr_t) * (size_t)n);
+    dst->length += n;
+}
+
+/* generate_query_terms (query.c:489-603) */
+static void generate_query_terms(m_query_t *q) {
+    q->num_terms = 0;
+    int nw = q->num_words;
+    if (nw == 0) return;
+    size_t tl = q->text ? strlen(q->text) : 0;
+    int ends_space = tl > 0 && q->text[tl - 1] == ' ';
+    if (nw == 1) {
+        m_term_t *t = &q->terms[q->num_terms++];
+        memset(t, 0, sizeof(*t));
+        t->word = q->words[0];
+        if (q->cfg.prefix != MPREFIX_NONE) t->prefix = 1;
+        if (q->cfg.typos == MTYPO_OK && t->word.length > M_LEVLIMIT) t->typos = 1;
+        if (ends_space) t->prefix = 0;
+        return;
+    }
+    if (nw == 2) {
+        for (int i = 0; i < 2; i++) {
+            m_term_t *t = &q->terms[q->num_terms++];
+            memset(t, 0, sizeof(*t));
+            t->word = q->words[i];
+            if (q->cfg.prefix == MPREFIX_ALL) t->prefix = 1;
+            else if (q->cfg.prefix == MPREFIX_LAST && i == 1) t->prefix = ends_space ? 0 : 1;
+            if (q->cfg.typos == MTYPO_OK && t->word.length > M_LEVLIMIT) t->typos = 1;
+        }
+        m_term_t *t = &q->terms[q->num_terms++];
+        memset(t, 0, sizeof(*t));
+        t->word = q->words[0];
+        word_cat(&t->word, &q->words[1]);
+        t->typos = 0;
+        if (q->cfg.prefix != MPREFIX_NONE) t->prefix = 1;
+        return;
+    }
+    m_term_t ct;
+    memset(&ct, 0, sizeof(ct));
+    if (q->cfg.prefix != MPREFIX_NONE) ct.prefix = 1;
+    for (int i = 0; i < nw; i++) {
+        word_cat(&ct.word, &q->words[i]);
+        m_term_t *t = &q->terms[q->num_terms++];
+        memset(t, 0, sizeof(*t));
+        t->word = q->words[i];
+        if (q->cfg.typos == MTYPO_OK && t->word.length > M_LEVLIMIT) t->typos = 1;
+        if (q->cfg.prefix == MPREFIX_ALL) t->prefix = 1;
+        else if (q->cfg.prefix == MPREFIX_LAST && i == nw - 1) t->prefix = ends_space ? 0 : 1;
+        if (i != nw - 1) {
+            m_term_t *tt = &q->terms[q->num_terms++];
+            memset(tt, 0, sizeof(*tt));
+            tt->word = q->words[i];
+            word_cat(&tt->word, &q->words[i + 1]);
+            if (q->cfg.prefix != MPREFIX_NONE && i + 2 == nw) tt->prefix = 1;
+        }
+    }
+    q->terms[q->num_terms++] = ct;
+}
+
+int mq_set_text(m_query_t *q, const char *text) {
+    free(q->text);
+    q->text = text ? strdup(text) : NULL;
+    q->num_words = 0;
+    q->num_terms = 0;
+    if (text) m_analyze_for_search(text, word_cb, q);
+    if (q->num_words > M_MAX_QWORDS) { q->num_words = 0; return -1; }
+    generate_query_terms(q);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ comparators */
+bool m_rank_lt(const m_docrank_t *a, const m_docrank_t *b, const int *rules) {
+    for (int c = 0;; c++) {
+        switch (rules[c]) {
+            case MR_TYPO:  if (a->typos != b->typos) return a->typos < b->typos; break;
+            case MR_PROX:  if (a->proximity != b->proximity) return a->proximity < b->proximity; break;
+            case MR_POS:   if (a->position != b->position) return a->position < b->position; break;
+            case MR_EXACT: if (a->exact != b->exact) return a->exact > b->exact; break;
+            case MR_COMP:  if (a->compare != b->compare) return a->compare > b->compare; break;
+            case MR_COMP_ASC: if (a->compare != b->compare) return a->compare < b->compare; break;
+            case MR_FIELD: if (a->field != b->field) return a->field < b->field; break;
+            case MR_GEO:   if (a->distance != b->distance) return a->distance < b->distance; break;
+            default: return false;
+        }
+    }
+}
+
+bool m_rank_lt_canonical(const m_docrank_t *a, const m_docrank_t *b, const int *rules) {
+    if (m_rank_lt(a, b, rules)) return true;
+    if (m_rank_lt(b, a, rules)) return false;
+    if (a->shard_id != b->shard_id) return a->shard_id < b->shard_id;
+    return a->docid < b->docid;
+}
+
+/* bottom-up merge sort on the canonical order */
+void m_rank_sort_canonical(m_docrank_t *a, size_t n, const int *rules) {
+    if (n < 2) return;
+    m_docrank_t *tmp = malloc(n * sizeof(m_docrank_t));
+    m_docrank_t *src = a, *dst = tmp;
+    for (size_t w = 1; w < n; w *= 2) {
+        for (size_t lo = 0; lo < n; lo += 2 * w) {
+            size_t mid = lo + w < n ? lo + w : n, hi = lo + 2 * w < n ? lo + 2 * w : n;
+            size_t i = lo, j = mid, k = lo;
+            while (i < mid && j < hi) dst[k++] = m_rank_lt_canonical(&src[j], &src[i], rules) ? src[j++] : src[i++];
+            while (i < mid) dst[k++] = src[i++];
+            while (j < hi) dst[k++] = src[j++];
+        }
+        m_docrank_t *t = src; src = dst; dst = t;
+    }
+    if (src != a) memcpy(a, src, n * sizeof(m_docrank_t));
+    free(tmp);
+}
+
+static int cmp_fc(const void *pa, const void *pb) {
+    const m_facet_count_t *a = pa, *b = pb;
+    if (a->count != b->count) return a->count > b->count ? -1 : 1;
+    if (a->facet_id != b->facet_id) return a->facet_id < b->facet_id ? -1 : 1;
+    return 0;
+}
+
+static int cmp_u32(const void *a, const void *b) {
+    uint32_t x = *(const uint32_t *)a, y = *(const uint32_t *)b;
+    return x < y ? -1 : (x > y);
+}
+
+/* *_agg_merge (metric-aggs.c:66-73, 178-189, 245-250, 304-310, 365-371) */
+static void agg_merge(m_agg_t *into, const m_agg_t *from) {
+    switch (into->type) {
+        case MA_MAX: if (from->value > into->value) into->value = from->value; break;
+        case MA_MIN: if (from->value < into->value) into->value = from->value; break;
+        case MA_AVG: into->sum += from->sum; into->count += from->count; break;
+        case MA_STATS:
+            into->sum += from->sum; into->count += from->count;
+            if (from->min < into->min) into->min = from->min;
+            if (from->max > into->max) into->max = from->max;
+            break;
+        case MA_CARDINALITY: {
+            /* oper_or of the per-shard facet-id bitmaps == sorted set union */
+            uint32_t n = into->card_n + from->card_n;
+            uint32_t *u = malloc((n ? n : 1) * sizeof(uint32_t));
+            if (into->card_n) memcpy(u, into->card_ids, into->card_n * sizeof(uint32_t));
+            if (from->card_n) memcpy(u + into->card_n, from->card_ids, from->card_n * sizeof(uint32_t));
+            qsort(u, n, sizeof(uint32_t), cmp_u32);
+            uint32_t m = 0;
+            for (uint32_t i = 0; i < n; i++) if (i == 0 || u[i] != u[i - 1]) u[m++] = u[i];
+            free(into->card_ids);
+            into->card_ids = u; into->card_n = m;
+        } break;
+        default: break;
+    }
+}
+
+void m_form_result(const m_query_t *q, m_sqresult_t *sq, int num_shards, m_result_t *out) {
+    memset(out, 0, sizeof(*out));
+    out->full_scan = true;
+    int total_hits = 0, total_ranks = 0;
+    for (int i = 0; i < num_shards; i++) {
+        total_hits += (int)sq[i].num_hits;
+        total_ranks += sq[i].rank_count;
+        if (sq[i].fast_rank) out->full_scan = false;
+    }
+    int page_s = q->cfg.hits_per_page * (q->page_num - 1);
+    if (page_s > total_hits) page_s = total_hits;
+    int page_e = page_s + q->cfg.hits_per_page;
+    if (page_e > total_hits) page_e = total_hits;
+    out->total_hits = total_hits;
+    out->page_s = page_s; out->page_e = page_e;
+    out->num_hits = page_e - page_s;
+
+    /* ranks: concat with shard_id stamped, then sort (query.c:343-378) */
+    out->ranks = malloc((total_ranks ? total_ranks : 1) * sizeof(m_docrank_t));
+    int pos = 0;
+    for (int i = 0; i < num_shards; i++) {
+        for (int j = 0; j < sq[i].rank_count; j++) {
+            out->ranks[pos] = sq[i].ranks[j];
+            out->ranks[pos].shard_id = (uint8_t)i;
+            pos++;
+        }
+    }
+    out->total_ranks = total_ranks;
+    m_rank_sort_canonical(out->ranks, (size_t)total_ranks, q->rank_rule);
+
+    /* aggs: merged in shard order into the query's fresh aggs (query.c:373-375) */
+    out->num_aggs = q->num_aggs;
+    for (int a = 0; a < q->num_aggs; a++) {
+        if (num_shards == 1) {
+            out->aggs[a] = sq[0].aggs[a];
+            if (sq[0].aggs[a].card_n) {
+                out->aggs[a].card_ids = malloc(sq[0].aggs[a].card_n * sizeof(uint32_t));
+                memcpy(out->aggs[a].card_ids, sq[0].aggs[a].card_ids, sq[0].aggs[a].card_n * sizeof(uint32_t));
+            } else out->aggs[a].card_ids = NULL;
+        } else {
+            out->aggs[a] = q->aggs[a];
+            out->aggs[a].card_ids = NULL; out->aggs[a].card_n = 0;
+            for (int i = 0; i < num_shards; i++) agg_merge(&out->aggs[a], &sq[i].aggs[a]);
+        }
+    }
+
+    /* facets (query.c:39-92): sum each shard's top-2N lists by facet id, sort, cut to N */
+    int nf = 0;
+    for (int i = 0; i < num_shards; i++) if (sq[i].num_facets > nf) nf = sq[i].num_facets;
+    out->num_facets = nf;
+    for (int f = 0; f < nf; f++) {
+        if (!q->cfg.facet_enabled[f]) continue;
+        int cap = 0;
+        for (int i = 0; i < num_shards; i++) cap += sq[i].rcount[f];
+        m_facet_count_t *fc = malloc((cap ? cap : 1) * sizeof(m_facet_count_t));
+        int rcount = 0;
+        for (int i = 0; i < num_shards; i++) {
+            for (int j = 0; j < sq[i].rcount[f]; j++) {
+                const m_facet_count_t *ifc = &sq[i].fc[f][j];
+                int k;
+                for (k = 0; k < rcount; k++) if (fc[k].facet_id == ifc->facet_id) break;
+                if (k < rcount) fc[k].count += ifc->count;
+                else { fc[rcount] = *ifc; fc[rcount].shard_id = (uint8_t)i; rcount++; }
+            }
+        }
+        qsort(fc, (size_t)rcount, sizeof(m_facet_count_t), cmp_fc);
+        if (rcount > q->cfg.max_facet_results) rcount = q->cfg.max_facet_results;
+        out->fc[f] = fc;
+        out->fcount[f] = rcount;
+    }
+}
+
+void m_result_free(m_result_t *r) {
+    free(r->ranks);
+    for (int f = 0; f < M_MAX_FIELDS; f++) free(r->fc[f]);
+    for (int a = 0; a < r->num_aggs; a++) free(r->aggs[a].card_ids);
+    memset(r, 0, sizeof(*r));
+}
+
+/* struct sizes, so language bindings can verify their mirrors */
+size_t m_sizeof(int which) {
+    switch (which) {
+        case 0: return sizeof(m_docrank_t);
+        case 1: return sizeof(m_facet_count_t);
+        case 2: return sizeof(m_agg_t);
+        case 3: return sizeof(m_query_cfg_t);
+        case 4: return sizeof(m_query_t);
+        case 5: return sizeof(m_sqresult_t);
+        case 6: return sizeof(m_result_t);
+        case 7: return sizeof(m_filter_t);
+        case 8: return sizeof(m_word_t);
+        case 9: return sizeof(m_term_t);
+        default: return 0;
+    }
+}

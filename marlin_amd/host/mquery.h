@@ -1,0 +1,63 @@
+/* mquery.h -- query construction and cross-shard merge, host side.
+ *
+ * Mirrors the reference's query objects for this path: query_new / default query_cfg
+ * (index.c:1365-1378), analyze + generate_query_terms (index.c:1150-1156, query.c:489-603),
+ * rank_rule assembly (index.c:1134-1148) and the merge half of form_result
+ * (query.c:312-383, 39-92).  JSON parsing, hit materialisation and highlighting stay in
+ * the reference (out of scope).
+ */
+#ifndef MARLIN_AMD_MQUERY_H
+#define MARLIN_AMD_MQUERY_H
+
+#include "mcommon.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+m_query_t *mq_new(int num_facets);                 /* defaults of query_config_new */
+void       mq_free(m_query_t *q);
+/* q->text = text; words via the search analyzer; terms via generate_query_terms.
+ * returns 0, or -1 when the query has more than M_MAX_QWORDS words */
+int        mq_set_text(m_query_t *q, const char *text);
+/* call after cfg.rank_by / rank_sort / rank_asc / rank_algo are final (index.c:1134-1148) */
+void       mq_build_rank_rule(m_query_t *q);
+
+m_filter_t *mf_new(int type);
+void        mf_add_child(m_filter_t *parent, m_filter_t *child);
+void        mf_free(m_filter_t *f);
+
+int  mq_add_agg(m_query_t *q, int type, int field);
+
+/* merged result of one query over all shards (the non-JSON part of form_result) */
+typedef struct m_result {
+    int          total_hits;
+    int          num_hits;                          /* hits on the requested page */
+    int          page_s, page_e;
+    int          total_ranks;
+    m_docrank_t *ranks;                             /* all merged ranks, sorted; page = [page_s,page_e) */
+    int          num_facets;
+    int          fcount[M_MAX_FIELDS];
+    m_facet_count_t *fc[M_MAX_FIELDS];
+    int          num_aggs;
+    m_agg_t      aggs[M_MAX_AGGS];
+    bool         full_scan;
+} m_result_t;
+
+/* form_result, merge part (query.c:312-383) + process_facet_results (query.c:39-92).
+ * sq[i] is shard i's result.  Ordering among equal keys is canonical here (docs of equal
+ * rank by shard then docid; facets of equal count by facet id) where the reference's is
+ * implementation-defined -- see DESIGN.md "ties". */
+void m_form_result(const m_query_t *q, m_sqresult_t *sq, int num_shards, m_result_t *out);
+void m_result_free(m_result_t *r);
+
+/* __sort_lt (sort.c:46-100) */
+bool m_rank_lt(const m_docrank_t *a, const m_docrank_t *b, const int *rules);
+/* total order used wherever this implementation must break the reference's ties */
+bool m_rank_lt_canonical(const m_docrank_t *a, const m_docrank_t *b, const int *rules);
+void m_rank_sort_canonical(m_docrank_t *a, size_t n, const int *rules);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

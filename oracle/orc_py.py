@@ -1,0 +1,48 @@
+"""ctypes binding of the CPU oracle (oracle/liborc.so).  TEST INFRASTRUCTURE ONLY.
+
+May be imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg -- never by
+marlin_amd/.  See oracle/orc.h for what the oracle restates and how it is pinned.
+"""
+import ctypes as C
+import os
+
+from marlin_amd import ffi
+from marlin_amd.engine import assemble, shard_results_to_py
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        ffi.load()
+        path = os.path.join(_HERE, "liborc.so")
+        if not os.path.exists(path):
+            raise RuntimeError("oracle/liborc.so is missing: run `make oracle`")
+        lib = C.CDLL(path)
+        lib.orc_execute_squery.restype = C.c_int
+        lib.orc_execute_squery.argtypes = [C.c_void_p, C.POINTER(ffi.Query), C.c_int, C.c_int, C.POINTER(ffi.SqResult)]
+        _lib = lib
+    return _lib
+
+
+def execute_raw(index, pq, flags=0):
+    lib = load()
+    outs = (ffi.SqResult * index.num_shards)()
+    for s in range(index.num_shards):
+        rc = lib.orc_execute_squery(index.shards[s], pq.q, s, flags, C.byref(outs[s]))
+        if rc:
+            raise RuntimeError("orc_execute_squery: %d" % rc)
+    return outs
+
+
+def search(index, pq, flags=0):
+    """the oracle's answer for one parsed query, assembled like the GPU path's"""
+    outs = execute_raw(index, pq, flags)
+    r = assemble(index, pq, outs)
+    if flags:
+        r["_shards"] = shard_results_to_py(index, pq, outs)
+    for s in range(index.num_shards):
+        index.lib.m_sqresult_free(C.byref(outs[s]))
+    return r
