@@ -1,0 +1,96 @@
+"""helpers shared by the CPU and GPU test suites"""
+import json
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+ROBOT_SUITES = ["rank", "rank2", "rank3", "rank4", "rank5", "rank6", "rank7", "rank_terms",
+                "levenshtein", "terms", "filter_apply", "aggs", "facet", "sort"]
+
+
+def load_fixture(name):
+    with open(os.path.join(GOLDEN, "robot_%s.json" % name)) as f:
+        return json.load(f)
+
+
+def jpath(obj, path):
+    """evaluates the small JSONPath subset the robot suites use: $.a.b[0].c"""
+    assert path.startswith("$")
+    cur = obj
+    for m in re.finditer(r"\.([A-Za-z_][A-Za-z0-9_]*)|\[(\d+)\]", path[1:]):
+        cur = cur[m.group(1)] if m.group(1) is not None else cur[int(m.group(2))]
+    return cur
+
+
+def rank_key(r):
+    return (r["typos"], r["proximity"], r["field"], r["position"], r["exact"], r["compare"])
+
+
+def facets_canonical(res):
+    return {k: sorted(((e["count"], e["facet_id"]) for e in v), key=lambda t: (-t[0], t[1]))
+            for k, v in res["facets"].items()}
+
+
+def datagen_index(rend=10000, seed=12345):
+    """the reference's test corpus (test/data_gen.py) built by the C generator"""
+    import ctypes as C
+    from marlin_amd import Index, ffi
+    lib = ffi.load()
+    facets = open(os.path.join(GOLDEN, "facet.txt")).read().splitlines()
+    arr = (C.c_char_p * len(facets))(*[f.encode() for f in facets])
+    counts = (C.c_uint32 * len(facets))()
+    sh = lib.msynth_datagen(rend, seed, arr, len(facets), counts)
+    settings = {"hitsPerPage": 25}
+    ix = Index.from_shards(settings, [sh], ["str", "strlist", "facet", "facetlist", "spell"],
+                           ["id", "num", "numlist"], ["bool"], ["facet", "facetlist", "facetonly"])
+    ix.fields["numlist"].type = "numlist"
+    fcount = {}
+    for f, c in zip(facets, counts):
+        if c:
+            fcount[f] = fcount.get(f, 0) + c
+    return ix, fcount
+
+
+def compare_results(gpu, orc, ctx=""):
+    """GPU result vs oracle result for one query (both assembled with capture flags 3).
+
+    Exact where the reference defines the answer; tie-class aware where it does not
+    (DESIGN.md "ties"): equal rank keys may carry different docids, facets of equal count at
+    the cut may differ."""
+    assert gpu["totalHits"] == orc["totalHits"], ctx
+    assert gpu["numHits"] == orc["numHits"], ctx
+    # stage level: bitmap words and every per-document rank record
+    for s, (gs, os_) in enumerate(zip(gpu["_shards"], orc["_shards"])):
+        assert gs["num_hits"] == os_["num_hits"], (ctx, s)
+        if "docid_map" in gs and "docid_map" in os_:
+            assert gs["docid_map"] == os_["docid_map"], (ctx, s, "docid_map")
+        if "all_ranks" in gs and "all_ranks" in os_:
+            assert len(gs["all_ranks"]) == len(os_["all_ranks"]), (ctx, s)
+            for a, b in zip(gs["all_ranks"], os_["all_ranks"]):
+                assert a == b, (ctx, s, "rank record", a, b)
+        assert gs["rank_count"] == os_["rank_count"], (ctx, s)
+        for a, b in zip(gs["aggs"], os_["aggs"]):
+            assert a == b, (ctx, s, "agg", a, b)
+    # merged order: identical key sequence; docids identical wherever the key is unique
+    gk = [rank_key(r) for r in gpu["ranks"]]
+    ok = [rank_key(r) for r in orc["ranks"]]
+    assert gk == ok, ctx
+    for i, (a, b) in enumerate(zip(gpu["ranks"], orc["ranks"])):
+        if gk.count(gk[i]) == 1 and not _boundary_tie(gpu, i):
+            assert (a["shard"], a["docid"]) == (b["shard"], b["docid"]), (ctx, i)
+    # facets: same counts everywhere; same ids above the cut-off count
+    gf, of = facets_canonical(gpu), facets_canonical(orc)
+    assert gf.keys() == of.keys(), ctx
+    for k in gf:
+        assert [c for c, _ in gf[k]] == [c for c, _ in of[k]], (ctx, k)
+        if gf[k]:
+            cut = gf[k][-1][0]
+            assert [e for e in gf[k] if e[0] > cut] == [e for e in of[k] if e[0] > cut], (ctx, k)
+    assert gpu.get("aggs") == orc.get("aggs"), ctx
+
+
+def _boundary_tie(res, i):
+    """the last returned key may tie with documents that were cut"""
+    return i == len(res["ranks"]) - 1 and res["totalHits"] > len(res["ranks"])
