@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""bench.py -- queries/sec of the Marlin shard-query hot path on MI355X.
+
+Workload (BASELINE.json `metric` / configs[2]): a 10M-document synthetic Zipf index in 8 shards,
+a stream of 3-term queries (two typo'd frequent words + a 3-letter prefix, i.e. 6 terms with
+typo / prefix expansion), facets on 2 fields (64 and 100k buckets), rankBy a unique numeric
+field, top-10, fullScan.  A "step" is one batch of queries taken through execute_squery on every
+shard (plan lowering + GPU launches) and the form_result merge.
+
+  N = 1 : all 8 shards on one GPU.
+  N > 1 : shards split over the ranks (8/N each, fixed corpus => strong scaling); every rank runs
+          the whole query batch on its shards, per-shard result slots are gathered to rank 0 with
+          RCCL (torch.distributed all_gather over xGMI) and merged there.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant
+kernel stage (HIP-event timed on the launch stream) and `cpu_baseline` (the C oracle = port of the
+reference's CPU path, 1 core, bounded sample).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SEED = 0x4D41524C494E
+VOCAB = 262144
+HC_BUCKETS = 100000
+TOTAL_SHARDS = 8
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def build_shards(lib, total_docs, my_shards):
+    out = [None] * len(my_shards)
+
+    def work(i, s):
+        out[i] = lib.msynth_zipf(total_docs, VOCAB, HC_BUCKETS, SEED, s, TOTAL_SHARDS)
+    th = [threading.Thread(target=work, args=(i, s)) for i, s in enumerate(my_shards)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    return out
+
+
+def zipf_word(lib, r):
+    buf = C.create_string_buffer(16)
+    lib.msynth_zipf_word(VOCAB, SEED, r, buf)
+    return buf.value.decode()
+
+
+def make_queries(lib, n):
+    """3-word queries: two of the 24 most frequent words with one substituted letter (typo
+    distance 1) + the first three letters of a frequent word (prefix -> twid posting)."""
+    import random
+    rng = random.Random(1234)
+    qs = []
+    for _ in range(n):
+        ws = []
+        for _ in range(2):
+            w = zipf_word(lib, rng.randrange(0, 24))
+            p = rng.randrange(1, len(w))
+            c = rng.choice([ch for ch in "abcdefghijklmnopqrstuvwxyz" if ch != w[p]])
+            ws.append(w[:p] + c + w[p + 1:])
+        pre = zipf_word(lib, rng.randrange(0, 64))[:3]
+        qs.append({"q": " ".join(ws + [pre]), "fullScan": True, "rankBy": {"num": "desc"},
+                   "hitsPerPage": 10, "maxFacetResults": 10})
+    return qs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--docs", type=int, default=10_000_000)
+    ap.add_argument("--batch", type=int, default=32, help="queries per step")
+    ap.add_argument("--cpu-queries", type=int, default=4)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if TOTAL_SHARDS % world:
+        raise SystemExit("--gpus must divide %d" % TOTAL_SHARDS)
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+
+    from marlin_amd import GpuEngine, Index, ffi
+    lib = ffi.load()
+    local = TOTAL_SHARDS // world
+    my_shards = list(range(rank * local, (rank + 1) * local))
+    t0 = time.time()
+    shards = build_shards(lib, args.docs, my_shards)
+    ix = Index.from_shards({}, shards, ["str"], ["num", "price"], ["flag"], ["cat", "hc"])
+    t_build = time.time() - t0
+    t0 = time.time()
+    eng = GpuEngine(ix, device=local_rank)
+    t_mirror = time.time() - t0
+    lib.msq_set_plan_threads(min(16, max(1, (os.cpu_count() or 8) // max(world, 1))))
+    mirror_bytes = sum(lib.mgpu_shard_bytes(lib.mmirror_gpu(m)) for m in eng.mirrors)
+
+    nq_pool = 256
+    pool = [ix.query(j) for j in make_queries(lib, nq_pool)]
+    B = args.batch
+    K_TOP, NF, FMAX, NAGG = 10, 2, 20, 0
+    slot_b = lib.m_slot_bytes(K_TOP, NF, FMAX, NAGG)
+
+    def batch_queries(step):
+        return [pool[(step * B + i) % nq_pool] for i in range(B)]
+
+    gather_buf = None
+    if world > 1:
+        send = torch.empty(B * local * slot_b, dtype=torch.uint8, device="cuda")
+        recv = torch.empty(world * B * local * slot_b, dtype=torch.uint8, device="cuda")
+        host_send = torch.empty(B * local * slot_b, dtype=torch.uint8).pin_memory()
+        host_recv = torch.empty(world * B * local * slot_b, dtype=torch.uint8).pin_memory()
+
+    def run_step(step):
+        pqs = batch_queries(step)
+        qarr = (C.POINTER(ffi.Query) * B)(*[p.q for p in pqs])
+        outs = eng.execute_raw(pqs)
+        hits = 0
+        if world == 1:
+            hits = lib.m_form_result_batch(qarr, outs, B, local, None, 0)
+        else:
+            lib.m_slot_pack_batch(outs, B * local, K_TOP, NF, FMAX, NAGG, host_send.data_ptr())
+            send.copy_(host_send, non_blocking=True)
+            dist.all_gather_into_tensor(recv, send)
+            if rank == 0:
+                host_recv.copy_(recv, non_blocking=True)
+                torch.cuda.synchronize()
+                sq = (ffi.SqResult * (B * TOTAL_SHARDS))()
+                lib.m_slot_unpack_gathered(host_recv.data_ptr(), world, B, local, K_TOP, NF, FMAX, NAGG, sq)
+                hits = lib.m_form_result_batch(qarr, sq, B, TOTAL_SHARDS, None, 0)
+                for i in range(B * TOTAL_SHARDS):
+                    lib.m_sqresult_free(C.byref(sq[i]))
+        eng.free_raw(outs)
+        return hits
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for s in range(args.warmup):
+        run_step(s)
+    barrier()
+    t0 = time.perf_counter()
+    total_hits = 0
+    for s in range(args.steps):
+        total_hits += run_step(args.warmup + s)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    qps = args.steps * B / dt
+
+    # ---- single-query latency (batch of 1, unloaded), p50 / p99 over 200 queries
+    lat = []
+    if world == 1:
+        for i in range(200):
+            pq = pool[i % nq_pool]
+            qa = (C.POINTER(ffi.Query) * 1)(pq.q)
+            t1 = time.perf_counter()
+            o = eng.execute_raw([pq])
+            lib.m_form_result_batch(qa, o, 1, local, None, 0)
+            lat.append((time.perf_counter() - t1) * 1e3)
+            eng.free_raw(o)
+        lat.sort()
+
+    # ---- roofline of the dominant kernel stage: HIP events on the launch stream, profiled batches
+    roof = None
+    stage_tab = {}
+    eng.set_profiling(True)
+    acc = {}
+    nprof = 5
+    for s in range(nprof):
+        o = eng.execute_raw(batch_queries(s))
+        eng.free_raw(o)
+        tm = eng.timing()
+        for name, v in tm["stages"].items():
+            a = acc.setdefault(name, [0.0, 0])
+            a[0] += v["ms"]; a[1] += v["bytes"]
+    eng.set_profiling(False)
+    kernel_stages = [k for k in acc if k not in ("upload+clear", "download")]
+    dom = max(kernel_stages, key=lambda k: acc[k][0])
+    for k in acc:
+        ms, by = acc[k][0] / nprof, acc[k][1] / nprof
+        stage_tab[k] = {"ms": round(ms, 4), "MB": round(by / 1e6, 3), "GBps": round(by / ms / 1e6, 1) if ms > 0 else None}
+    ach = acc[dom][1] / acc[dom][0] / 1e6          # bytes / ms -> GB/s
+    roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+            "launch_ms": round(acc[dom][0] / nprof, 4), "algorithmic_MB_per_launch": round(acc[dom][1] / nprof / 1e6, 3)}
+
+    # ---- CPU baseline: the C oracle (port of the reference's execute_squery) on this host, 1 core
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        from oracle import orc_py
+        orc_py.load()
+        n = args.cpu_queries
+        t1 = time.perf_counter()
+        chk = 0
+        for i in range(n):
+            outs = orc_py.execute_raw(ix, pool[i])
+            chk += sum(outs[s].num_hits for s in range(local))
+            for s in range(local):
+                lib.m_sqresult_free(C.byref(outs[s]))
+        cdt = time.perf_counter() - t1
+        cpu = {"value": round(n / cdt, 3), "unit": "queries/s", "cores": 1, "kind": "port",
+               "sample": "%d of the bench queries, all 8 shards sequentially, oracle/orc_squery.c" % n,
+               "total_hits": chk}
+
+    if rank == 0:
+        line = {
+            "metric": "queries/sec, 10M-doc index, 3-term typo+prefix query w/ facets",
+            "value": round(qps, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "configs[2]: %d docs Zipf corpus, %d shards, 3-word typo+prefix query, 2 facet fields, "
+                                   "rankBy num desc, top-10, fullScan" % (args.docs, TOTAL_SHARDS),
+                       "queries_per_step": B, "shards_per_gpu": local, "vocab": VOCAB,
+                       "mean_hits_per_query": round(total_hits / max(1, args.steps * B), 1)},
+            "roofline": roof, "cpu_baseline": cpu,
+            "latency_ms": {"p50": round(lat[len(lat) // 2], 3), "p99": round(lat[int(len(lat) * 0.99)], 3)} if lat else None,
+            "stages": stage_tab,
+            "setup_s": {"build_shards": round(t_build, 1), "mirror": round(t_mirror, 1)},
+            "mirror_GB": round(mirror_bytes / 1e9, 3),
+        }
+        print(json.dumps(line), flush=True)
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

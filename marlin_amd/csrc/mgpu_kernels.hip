@@ -642,10 +642,28 @@ __global__ __launch_bounds__(MG_BLOCK) void k_select_pass(const SelJob *jobs) {
     for (uint32_t i = threadIdx.x; i < MG_SEL_BINS; i += MG_BLOCK)
         hist[i] = __hip_atomic_load(&job.hist[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
+    // parallel search of the bin where the running count crosses krem_now: 8 bins per thread
+    __shared__ uint32_t s_scan[8];
+    __shared__ uint32_t s_dstar;
+    if (threadIdx.x == 0) s_dstar = 0xFFFFFFFFu;
+    const uint32_t nbins = 1u << ncur;
+    constexpr uint32_t BPT = MG_SEL_BINS / MG_BLOCK;
+    uint32_t loc[BPT], lsum = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < BPT; j++) { loc[j] = hist[threadIdx.x * BPT + j]; lsum += loc[j]; }
+    uint32_t tot;
+    const uint32_t excl = block_excl_scan(lsum, &tot, s_scan);
+    if (excl < krem_now && excl + lsum >= krem_now) {
+        uint32_t acc = excl;
+#pragma unroll
+        for (uint32_t j = 0; j < BPT; j++) {
+            if (acc < krem_now && acc + loc[j] >= krem_now) s_dstar = threadIdx.x * BPT + j;
+            acc += loc[j];
+        }
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t acc = 0, d = 0;
-        const uint32_t nbins = 1u << ncur;
-        for (; d < nbins; d++) { if (acc + hist[d] >= krem_now) break; acc += hist[d]; }
+        uint32_t d = s_dstar;
         if (d >= nbins) d = nbins - 1;
         ctl[SEL_DSTAR] = d;
         ctl[SEL_BPREV] = bitpos;

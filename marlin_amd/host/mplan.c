@@ -4,6 +4,7 @@
 #include <string.h>
 #include <float.h>
 #include <stdio.h>
+#include <pthread.h>
 
 /* ------------------------------------------------------------------ mirror export */
 int mmirror_create(const mshard_t *s, int device, mmirror_t **out) {
@@ -302,6 +303,26 @@ int mplan_build(const mmirror_t *m, const m_query_t *q, int capture, mplan_t *pl
 }
 
 /* ------------------------------------------------------------------ execution */
+int msq_plan_threads = 1;
+void msq_set_plan_threads(int n) { msq_plan_threads = n; }
+
+struct plan_job {
+    mmirror_t *const *mirrors; int num_shards; const m_query_t *const *queries; int capture;
+    mplan_t *plans; mgpu_plan_t *gp; mgpu_shard_t **gs; int lo, hi, rc;
+};
+static void *plan_worker(void *arg) {
+    struct plan_job *j = arg;
+    for (int i = j->lo; i < j->hi; i++) {
+        int qi = i / j->num_shards, sidx = i % j->num_shards;
+        int rc = mplan_build(j->mirrors[sidx], j->queries[qi], j->capture, &j->plans[i]);
+        if (rc) j->rc = rc;
+        j->gp[i] = j->plans[i].p;
+        j->gs[i] = j->mirrors[sidx]->g;
+    }
+    return NULL;
+}
+
+mgpu_shard_t *mmirror_gpu(mmirror_t *m) { return m ? m->g : NULL; }
 int msq_execute_batch(mgpu_ctx_t *ctx, mmirror_t *const *mirrors, int num_shards,
                       const m_query_t *const *queries, int nq, int capture, m_sqresult_t *outs) {
     int n = nq * num_shards;
@@ -310,13 +331,25 @@ int msq_execute_batch(mgpu_ctx_t *ctx, mmirror_t *const *mirrors, int num_shards
     mgpu_shard_t **gs = calloc((size_t)n, sizeof(mgpu_shard_t *));
     mgpu_sqout_t *go = calloc((size_t)n, sizeof(mgpu_sqout_t));
     int rc = 0;
-    for (int qi = 0; qi < nq && !rc; qi++) {
-        for (int sidx = 0; sidx < num_shards && !rc; sidx++) {
-            int i = qi * num_shards + sidx;
-            rc = mplan_build(mirrors[sidx], queries[qi], capture, &plans[i]);
-            gp[i] = plans[i].p;
-            gs[i] = mirrors[sidx]->g;
+    {
+        /* lookup_terms for every (query, shard) pair: independent, so spread over host threads */
+        int nthreads = msq_plan_threads;
+        if (nthreads > n) nthreads = n;
+        if (nthreads < 1) nthreads = 1;
+        struct plan_job jobs[64];
+        pthread_t th[64];
+        if (nthreads > 64) nthreads = 64;
+        for (int t = 0; t < nthreads; t++) {
+            jobs[t].mirrors = mirrors; jobs[t].num_shards = num_shards; jobs[t].queries = queries;
+            jobs[t].capture = capture; jobs[t].plans = plans; jobs[t].gp = gp; jobs[t].gs = gs;
+            jobs[t].lo = (int)((long)n * t / nthreads); jobs[t].hi = (int)((long)n * (t + 1) / nthreads); jobs[t].rc = 0;
         }
+        if (nthreads == 1) plan_worker(&jobs[0]);
+        else {
+            for (int t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, plan_worker, &jobs[t]);
+            for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+        }
+        for (int t = 0; t < nthreads; t++) if (jobs[t].rc) rc = jobs[t].rc;
     }
     if (!rc) rc = mgpu_execute(ctx, gs, gp, n, go);
     for (int i = 0; i < n; i++) {

@@ -53,6 +53,10 @@ void mplan_free(mplan_t *pl);
 int  msq_execute_batch(mgpu_ctx_t *ctx, mmirror_t *const *mirrors, int num_shards,
                        const m_query_t *const *queries, int nq, int capture, m_sqresult_t *outs);
 
+/* host threads used for plan building inside msq_execute_batch (default 1) */
+void msq_set_plan_threads(int n);
+mgpu_shard_t *mmirror_gpu(mmirror_t *m);
+
 #ifdef __cplusplus
 }
 #endif

@@ -349,3 +349,91 @@ size_t m_sizeof(int which) {
         default: return 0;
     }
 }
+
+/* ------------------------------------------------------------------ result slots
+ * Fixed-size wire form of one shard's squery_result, for the cross-GPU gather that replaces
+ * the shared-memory hand-off of query.c:319-383.  Cardinality id sets are variable-length and
+ * are not carried (multi-GPU). */
+typedef struct m_slot_hdr {
+    uint32_t num_hits; int32_t rank_count; int32_t num_facets; int32_t num_aggs;
+    int32_t rcount[M_MAX_FIELDS];
+} m_slot_hdr_t;
+
+size_t m_slot_bytes(int k, int num_facets, int fmax, int num_aggs) {
+    size_t b = sizeof(m_slot_hdr_t) + (size_t)k * sizeof(m_docrank_t) +
+               (size_t)num_facets * (size_t)fmax * sizeof(m_facet_count_t) + (size_t)num_aggs * sizeof(m_agg_t);
+    return (b + 15) & ~(size_t)15;
+}
+
+void m_slot_pack(const m_sqresult_t *r, int k, int num_facets, int fmax, int num_aggs, uint8_t *buf) {
+    m_slot_hdr_t h;
+    memset(&h, 0, sizeof(h));
+    h.num_hits = r->num_hits; h.rank_count = r->rank_count < k ? r->rank_count : k;
+    h.num_facets = num_facets; h.num_aggs = num_aggs;
+    for (int f = 0; f < num_facets; f++) h.rcount[f] = r->rcount[f] < fmax ? r->rcount[f] : fmax;
+    memcpy(buf, &h, sizeof(h));
+    uint8_t *p = buf + sizeof(h);
+    if (h.rank_count) memcpy(p, r->ranks, (size_t)h.rank_count * sizeof(m_docrank_t));
+    p += (size_t)k * sizeof(m_docrank_t);
+    for (int f = 0; f < num_facets; f++) {
+        if (h.rcount[f]) memcpy(p, r->fc[f], (size_t)h.rcount[f] * sizeof(m_facet_count_t));
+        p += (size_t)fmax * sizeof(m_facet_count_t);
+    }
+    for (int a = 0; a < num_aggs; a++) {
+        m_agg_t ag = r->aggs[a]; ag.card_ids = NULL; ag.card_n = 0;
+        memcpy(p, &ag, sizeof(ag)); p += sizeof(ag);
+    }
+}
+
+void m_slot_unpack(const uint8_t *buf, int k, int num_facets, int fmax, int num_aggs, int shard_idx, m_sqresult_t *out) {
+    m_slot_hdr_t h;
+    memcpy(&h, buf, sizeof(h));
+    memset(out, 0, sizeof(*out));
+    out->num_hits = h.num_hits; out->rank_count = h.rank_count; out->num_facets = num_facets; out->num_aggs = num_aggs;
+    const uint8_t *p = buf + sizeof(h);
+    out->ranks = malloc((size_t)(h.rank_count ? h.rank_count : 1) * sizeof(m_docrank_t));
+    memcpy(out->ranks, p, (size_t)h.rank_count * sizeof(m_docrank_t));
+    p += (size_t)k * sizeof(m_docrank_t);
+    for (int f = 0; f < num_facets; f++) {
+        out->rcount[f] = h.rcount[f];
+        out->fc[f] = malloc((size_t)(h.rcount[f] ? h.rcount[f] : 1) * sizeof(m_facet_count_t));
+        memcpy(out->fc[f], p, (size_t)h.rcount[f] * sizeof(m_facet_count_t));
+        for (int x = 0; x < h.rcount[f]; x++) out->fc[f][x].shard_id = (uint8_t)shard_idx;
+        p += (size_t)fmax * sizeof(m_facet_count_t);
+    }
+    for (int a = 0; a < num_aggs; a++) { memcpy(&out->aggs[a], p, sizeof(m_agg_t)); p += sizeof(m_agg_t); }
+}
+
+/* pack / unpack / merge whole batches (one call per step from the launcher) */
+void m_slot_pack_batch(const m_sqresult_t *rs, int n, int k, int num_facets, int fmax, int num_aggs, uint8_t *buf) {
+    size_t sb = m_slot_bytes(k, num_facets, fmax, num_aggs);
+    for (int i = 0; i < n; i++) m_slot_pack(&rs[i], k, num_facets, fmax, num_aggs, buf + (size_t)i * sb);
+}
+
+/* gathered layout: [rank][query][local shard]; output: sq[query * total_shards + rank * local + s] */
+void m_slot_unpack_gathered(const uint8_t *buf, int nranks, int nq, int local_shards, int k, int num_facets,
+                            int fmax, int num_aggs, m_sqresult_t *sq) {
+    size_t sb = m_slot_bytes(k, num_facets, fmax, num_aggs);
+    int total = nranks * local_shards;
+    for (int r = 0; r < nranks; r++)
+        for (int q = 0; q < nq; q++)
+            for (int s = 0; s < local_shards; s++) {
+                int shard = r * local_shards + s;
+                m_slot_unpack(buf + (((size_t)r * nq + q) * local_shards + s) * sb, k, num_facets, fmax, num_aggs,
+                              shard, &sq[(size_t)q * total + shard]);
+            }
+}
+
+/* returns the sum of total_hits over the batch (a checksum the launcher prints) */
+long m_form_result_batch(const m_query_t *const *queries, m_sqresult_t *sq, int nq, int num_shards,
+                         m_result_t *outs, int keep) {
+    long hits = 0;
+    for (int q = 0; q < nq; q++) {
+        m_result_t tmp;
+        m_result_t *o = keep ? &outs[q] : &tmp;
+        m_form_result(queries[q], sq + (size_t)q * num_shards, num_shards, o);
+        hits += o->total_hits;
+        if (!keep) m_result_free(o);
+    }
+    return hits;
+}
