@@ -27,7 +27,8 @@ void mgk_row_op(hipStream_t st, const unsigned long long *a, const unsigned long
                 uint32_t W, int op, unsigned long long *card);
 }
 
-struct FkJob { const uint32_t *hist; const uint32_t *ord2id; uint32_t n; uint32_t pad; u64 *key_hi, *key_lo; };
+struct FkJob { const uint32_t *hist; const uint32_t *ord2id; uint32_t n; uint32_t pad; u64 *key_hi, *key_lo;
+               uint32_t *nnz; u64 *andor; };
 struct CardJob { const uint32_t *hist; const uint32_t *ord2id; uint32_t n; uint32_t pad; uint32_t *out_ids; uint32_t *out_n; };
 struct SelOut { u64 *out_hi, *out_lo; uint32_t *out_pl; const uint32_t *payload; };
 
@@ -411,7 +412,7 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
         size_t fkhi[MGPU_MAX_FIELDS], fklo[MGPU_MAX_FIELDS];
     };
     std::vector<Offs> offs(n);
-    struct SelOff { size_t cand0, cand1, hist, ctl, outidx; uint32_t mcap; };
+    struct SelOff { size_t cand0, cand1, hist, ctl, outidx, nnz, andor; uint32_t mcap; };
     std::vector<SelOff> seloff;
 
     for (int i = 0; i < n; i++) {
@@ -610,6 +611,7 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
             SelOff so; so.mcap = sd.fa_nord[f];
             so.cand0 = nz.take((size_t)so.mcap * 4); so.cand1 = nz.take((size_t)so.mcap * 4);
             so.hist = zer.take(MG_SEL_BINS * 4); so.ctl = zer.take(SEL_WORDS * 4); so.outidx = nz.take((size_t)MG_SEL_FINAL * 4);
+            so.nnz = zer.take(4, 4); so.andor = zer.take(32, 8);
             seloff.push_back(so); jobfix.push_back({i, 1, j});
             max_selm = std::max(max_selm, so.mcap);
         }
@@ -698,15 +700,13 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
             Offs &o = offs[jf.sq];
             q.fkey_hi[f] = (uint64_t *)(NZ + o.fkhi[f]); q.fkey_lo[f] = (uint64_t *)(NZ + o.fklo[f]);
             sj.key_hi = q.fkey_hi[f]; sj.key_lo = q.fkey_lo[f];
-            sj.m_ptr = &q.sh.fa_nord[f];   // patched below to a device address
-            sj.k = h.fac_k[jf.field]; sj.out_n = &hdr->fac_n[jf.field]; sj.mask = nullptr; sj.skip_ones = 1;
+            sj.m_ptr = (const uint32_t *)(Z + so.nnz);
+            sj.k = h.fac_k[jf.field]; sj.out_n = &hdr->fac_n[jf.field]; sj.mask = (const uint64_t *)(Z + so.andor); sj.skip_ones = 1;
             so2.out_hi = (u64 *)(R + h.fac_hi[jf.field]); so2.out_lo = (u64 *)(R + h.fac_lo[jf.field]);
             so2.out_pl = (uint32_t *)(R + h.fac_pl[jf.field]); so2.payload = nullptr;
-            // the bin count lives in the uploaded SqDev copy
-            const SqDev *dq = (const SqDev *)(UP + up_sq) + jf.sq;
-            sj.m_ptr = &dq->sh.fa_nord[f];
             FkJob fj; fj.hist = q.hist[f]; fj.ord2id = q.sh.fa_ord2id[f]; fj.n = q.sh.fa_nord[f]; fj.pad = 0;
             fj.key_hi = (u64 *)q.fkey_hi[f]; fj.key_lo = (u64 *)q.fkey_lo[f];
+            fj.nnz = (uint32_t *)(Z + so.nnz); fj.andor = (u64 *)(Z + so.andor);
             fkjobs.push_back(fj);
         }
     }
@@ -763,7 +763,7 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
     HIPCHK(hipGetLastError());
 
     // a selection that needed more than MG_SEL_PASSES passes: run further rounds
-    for (int round = 0; round < 8; round++) {
+    for (int round = 0; round < 20; round++) {
         bool again = false;
         for (size_t j = 0; j < seloff.size() && !again; j++) {
             const JobFix &jf = jobfix[j]; SqHost &h = sqh[jf.sq];
@@ -860,7 +860,7 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
             c->stage_bytes[4] += (uint64_t)(M * per);
         }
         for (int j = 0; j < h.nfac; j++) c->stage_bytes[5] += (uint64_t)q.sh.fa_nord[h.fac_field[j]] * 24;
-        if (h.k) c->stage_bytes[6] += 16 * M * (M > MG_SEL_FINAL ? 2 : 1);
+        if (h.k) c->stage_bytes[6] += 16 * M * (M > MG_SEL_SMALL ? 2 : 1);
     }
     c->stage_bytes[0] = up_bytes; c->stage_bytes[7] = res_bytes;
     return worst;

@@ -494,13 +494,33 @@ __global__ __launch_bounds__(64) void k_aggfinal(const SqDev *sqs) {
 }
 
 // facet bins -> selection keys: smaller key = larger count, ties by facet id (squery.c:411-437)
-struct FkJob { const uint32_t *hist; const uint32_t *ord2id; uint32_t n; uint32_t pad; u64 *key_hi, *key_lo; };
+struct FkJob { const uint32_t *hist; const uint32_t *ord2id; uint32_t n; uint32_t pad; u64 *key_hi, *key_lo;
+               uint32_t *nnz; u64 *andor; };
+// Only bins that were hit become keys (wave-ballot compaction), and the bits that differ between
+// keys are recorded so the radix select skips the constant ones.
 __global__ __launch_bounds__(MG_BLOCK) void k_fkeys(const FkJob *jobs) {
     const FkJob j = jobs[blockIdx.y];
-    for (uint32_t i = blockIdx.x * MG_BLOCK + threadIdx.x; i < j.n; i += gridDim.x * MG_BLOCK) {
-        const uint32_t c = j.hist[i];
-        j.key_hi[i] = c ? (u64)(0xFFFFFFFFu - c) : ~0ull;
-        j.key_lo[i] = j.ord2id[i];
+    const int lane = threadIdx.x & 63;
+    u64 a = 0, b = 0, na = 0, nb = 0;
+    for (uint32_t base = blockIdx.x * MG_BLOCK; base < j.n; base += gridDim.x * MG_BLOCK) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t c = (i < j.n) ? j.hist[i] : 0;
+        const bool nz = c != 0;
+        const u64 m = __ballot(nz);
+        uint32_t wbase = 0;
+        if (lane == 0 && m) wbase = atomicAdd(j.nnz, (uint32_t)__popcll(m));
+        wbase = __shfl(wbase, 0, 64);
+        if (nz) {
+            const uint32_t at = wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+            const u64 hi = (u64)(0xFFFFFFFFu - c), lo = j.ord2id[i];
+            j.key_hi[at] = hi; j.key_lo[at] = lo;
+            a |= hi; b |= lo; na |= ~hi; nb |= ~lo;
+        }
+    }
+    a = wave_or64(a); b = wave_or64(b); na = wave_or64(na); nb = wave_or64(nb);
+    if (lane == 0 && (a | b | na | nb)) {
+        atomicOr((u64 *)&j.andor[0], na); atomicOr((u64 *)&j.andor[1], nb);
+        atomicOr((u64 *)&j.andor[2], a);  atomicOr((u64 *)&j.andor[3], b);
     }
 }
 
@@ -553,148 +573,199 @@ __device__ __forceinline__ void job_masks(const SelJob &job, uint32_t M, u64 &mh
 }
 
 #define SEL_ITEMS 8
+#define SEL_CHUNK (MG_BLOCK * SEL_ITEMS)     // candidates per workgroup iteration
+#define SEL_SOLO_CHUNKS 16                   // a lone workgroup takes lists up to 32768 and runs every remaining pass in one launch
+#define SEL_SMALL_CAP MG_SEL_SMALL            // final sort sizes: small / big workgroup variant
+#define SEL_BIG_CAP (2 * MG_SEL_FINAL)
 // extra ctl words used by the passes
-enum { SEL_NIN = SEL_NCAND, SEL_DSTAR = SEL_NEXT, SEL_BPREV = 8, SEL_NOUT = 9, SEL_BUF = 10, SEL_NPREV = 11 };
+enum { SEL_NIN = SEL_NCAND, SEL_DSTAR = SEL_NEXT, SEL_BPREV = 8, SEL_NOUT = 9, SEL_BUF = 10, SEL_NPREV = 11, SEL_NFIN = 12 };
 
+__device__ __forceinline__ uint32_t sel_nblocks(uint32_t nin, uint32_t gdim) {
+    const uint32_t nch = (nin + SEL_CHUNK - 1) / SEL_CHUNK;
+    if (nch <= SEL_SOLO_CHUNKS) return 1;
+    return nch < gdim ? nch : gdim;
+}
+
+// One pass = filter the candidate list by the previous digit decision (winners below it go to the
+// output, the digit's own bucket stays a candidate) and histogram the survivors on the next digit;
+// the last workgroup to finish picks the bucket holding the k-th key.  Lists that fit one
+// workgroup (the common case: a shard's hits for one query) never come back to the host: that
+// workgroup keeps iterating passes in LDS until the answer fits the final sort.
 __global__ __launch_bounds__(MG_BLOCK) void k_select_pass(const SelJob *jobs) {
     const SelJob job = jobs[blockIdx.y];
     uint32_t *ctl = job.ctl;
     const uint32_t M = *job.m_ptr;
-    if (ctl[SEL_DONE]) return;
-    const uint32_t pass = ctl[SEL_PASS];
-    const uint32_t nin = (pass == 0) ? M : ctl[SEL_NIN];
-    const uint32_t krem = (pass == 0) ? job.k : ctl[SEL_KREM];
-    if (pass == 0 && (M <= MG_SEL_FINAL || job.k >= M)) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) { ctl[SEL_NIN] = M; ctl[SEL_KREM] = job.k; ctl[SEL_DONE] = 1; }
-        return;
-    }
-    const uint32_t per_block = MG_BLOCK * SEL_ITEMS;
-    const uint32_t nb_active = (nin + per_block - 1) / per_block;
-    if (blockIdx.x >= nb_active) return;
-
     __shared__ uint32_t hist[MG_SEL_BINS];
-    __shared__ uint32_t s_last;
-    for (uint32_t i = threadIdx.x; i < MG_SEL_BINS; i += MG_BLOCK) hist[i] = 0;
-
+    __shared__ uint32_t s_ctl[SEL_WORDS];
+    __shared__ uint32_t s_scan[8];
+    __shared__ uint32_t s_last, s_nout, s_nwin, s_dstar, s_cum;
     u64 mhi, mlo; uint32_t midx;
     job_masks(job, M, mhi, mlo, midx);
-    uint8_t pprev[MG_SEL_DIGIT], pcur[MG_SEL_DIGIT];
-    int nprev = 0; uint32_t dummy;
-    const uint32_t bitpos = (pass == 0) ? 0 : ctl[SEL_BITPOS];
-    if (pass > 0) nprev = digit_bits(mhi, mlo, midx, ctl[SEL_BPREV], pprev, &dummy);
-    uint32_t next_bitpos;
-    const int ncur = digit_bits(mhi, mlo, midx, bitpos, pcur, &next_bitpos);
-    const uint32_t dstar = ctl[SEL_DSTAR];
-    const uint32_t buf = ctl[SEL_BUF];
-    const uint32_t *rin = (pass <= 1) ? nullptr : job.cand[buf];
-    uint32_t *rout = job.cand[buf ^ (pass <= 1 ? 0u : 1u)];
-    uint32_t *win = job.out_idx;        // winners accumulate in the output buffer, sorted at the end
-    __syncthreads();
-
     const int lane = threadIdx.x & 63;
-    for (int it = 0; it < SEL_ITEMS; it++) {
-        const uint32_t i = blockIdx.x * per_block + it * MG_BLOCK + threadIdx.x;
-        bool keep = false, winner = false;
-        uint32_t idx = 0; u64 hi = 0, lo = 0;
-        if (i < nin) {
-            idx = rin ? rin[i] : i;
-            hi = job.key_hi[idx]; lo = job.key_lo[idx];
-            keep = true;
-            if (pass > 0) {
-                const uint32_t dp = digit_of(hi, lo, idx, pprev, nprev);
-                if (dp < dstar) { winner = true; keep = false; }
-                else if (dp > dstar) keep = false;
+    uint32_t vbid = blockIdx.x;
+    bool continuing = false;
+
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x < SEL_WORDS) s_ctl[threadIdx.x] = __hip_atomic_load(&ctl[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (s_ctl[SEL_DONE]) return;
+        const uint32_t pass = s_ctl[SEL_PASS];
+        const uint32_t nin = (pass == 0) ? M : s_ctl[SEL_NIN];
+        if (pass == 0 && (M <= SEL_SMALL_CAP || job.k >= M)) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) { ctl[SEL_NIN] = M; ctl[SEL_KREM] = job.k; ctl[SEL_NFIN] = M; ctl[SEL_DONE] = 1; }
+            return;
+        }
+        const uint32_t nb = sel_nblocks(nin, gridDim.x);
+        if (!continuing && vbid >= nb) return;
+        const bool solo = nb == 1;
+
+        for (uint32_t i = threadIdx.x; i < MG_SEL_BINS; i += MG_BLOCK) hist[i] = 0;
+        if (threadIdx.x == 0) { s_nout = 0; s_nwin = s_ctl[SEL_NWIN]; s_dstar = 0xFFFFFFFFu; s_cum = 0; }
+        uint8_t pprev[MG_SEL_DIGIT], pcur[MG_SEL_DIGIT];
+        int nprev = 0; uint32_t dummy;
+        const uint32_t bitpos = (pass == 0) ? 0 : s_ctl[SEL_BITPOS];
+        if (pass > 0) nprev = digit_bits(mhi, mlo, midx, s_ctl[SEL_BPREV], pprev, &dummy);
+        uint32_t next_bitpos;
+        const int ncur = digit_bits(mhi, mlo, midx, bitpos, pcur, &next_bitpos);
+        const uint32_t dstar = s_ctl[SEL_DSTAR];
+        const uint32_t buf = s_ctl[SEL_BUF];
+        const uint32_t *rin = (pass <= 1) ? nullptr : job.cand[buf];
+        uint32_t *rout = job.cand[buf ^ (pass <= 1 ? 0u : 1u)];
+        uint32_t *win = job.out_idx;        // winners accumulate in the output buffer, sorted at the end
+        __syncthreads();
+
+        const uint32_t nch = (nin + SEL_CHUNK - 1) / SEL_CHUNK;
+        for (uint32_t ch = vbid; ch < nch; ch += nb) {
+#pragma unroll 2
+            for (int it = 0; it < SEL_ITEMS; it++) {
+                const uint32_t i = ch * SEL_CHUNK + it * MG_BLOCK + threadIdx.x;
+                bool keep = false, winner = false;
+                uint32_t idx = 0; u64 hi = 0, lo = 0;
+                if (i < nin) {
+                    idx = rin ? rin[i] : i;
+                    hi = job.key_hi[idx]; lo = job.key_lo[idx];
+                    keep = true;
+                    if (pass > 0) {
+                        const uint32_t dp = digit_of(hi, lo, idx, pprev, nprev);
+                        if (dp < dstar) { winner = true; keep = false; }
+                        else if (dp > dstar) keep = false;
+                    }
+                }
+                if (pass > 0) {
+                    // wave-aggregated appends
+                    const u64 mk = __ballot(keep), mw = __ballot(winner);
+                    uint32_t bk = 0, bw = 0;
+                    if (lane == 0) {
+                        if (solo) {
+                            if (mk) bk = atomicAdd(&s_nout, (uint32_t)__popcll(mk));
+                            if (mw) bw = atomicAdd(&s_nwin, (uint32_t)__popcll(mw));
+                        } else {
+                            if (mk) bk = atomicAdd(&ctl[SEL_NOUT], (uint32_t)__popcll(mk));
+                            if (mw) bw = atomicAdd(&ctl[SEL_NWIN], (uint32_t)__popcll(mw));
+                        }
+                    }
+                    bk = __shfl(bk, 0, 64); bw = __shfl(bw, 0, 64);
+                    const u64 below = (1ull << lane) - 1;
+                    if (keep) rout[bk + (uint32_t)__popcll(mk & below)] = idx;
+                    if (winner) win[bw + (uint32_t)__popcll(mw & below)] = idx;
+                }
+                if (keep) atomicAdd(&hist[digit_of(hi, lo, idx, pcur, ncur)], 1u);
             }
         }
-        if (pass > 0) {
-            // wave-aggregated appends
-            const u64 mk = __ballot(keep), mw = __ballot(winner);
-            uint32_t bk = 0, bw = 0;
-            if (lane == 0) {
-                if (mk) bk = atomicAdd(&ctl[SEL_NOUT], (uint32_t)__popcll(mk));
-                if (mw) bw = atomicAdd(&ctl[SEL_NWIN], (uint32_t)__popcll(mw));
+        __syncthreads();
+        uint32_t nwin_total, nkept;
+        if (!solo) {
+            for (uint32_t i = threadIdx.x; i < MG_SEL_BINS; i += MG_BLOCK) {
+                const uint32_t c = hist[i];
+                if (c) atomicAdd(&job.hist[i], c);
             }
-            bk = __shfl(bk, 0, 64); bw = __shfl(bw, 0, 64);
-            const u64 below = (1ull << lane) - 1;
-            if (keep) rout[bk + (uint32_t)__popcll(mk & below)] = idx;
-            if (winner) win[bw + (uint32_t)__popcll(mw & below)] = idx;
+            __threadfence();
+            __syncthreads();
+            if (threadIdx.x == 0) s_last = (atomicAdd(&ctl[SEL_TICKET], 1u) == nb - 1) ? 1u : 0u;
+            __syncthreads();
+            if (!s_last) return;
+            // last workgroup of this pass
+            __threadfence();
+            for (uint32_t i = threadIdx.x; i < MG_SEL_BINS; i += MG_BLOCK) {
+                hist[i] = __hip_atomic_load(&job.hist[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                job.hist[i] = 0;
+            }
+            nwin_total = __hip_atomic_load(&ctl[SEL_NWIN], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            nkept = (pass == 0) ? M : __hip_atomic_load(&ctl[SEL_NOUT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+        } else {
+            nwin_total = s_nwin;
+            nkept = (pass == 0) ? M : s_nout;
         }
-        if (keep) atomicAdd(&hist[digit_of(hi, lo, idx, pcur, ncur)], 1u);
-    }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < MG_SEL_BINS; i += MG_BLOCK) {
-        const uint32_t c = hist[i];
-        if (c) atomicAdd(&job.hist[i], c);
-    }
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = (atomicAdd(&ctl[SEL_TICKET], 1u) == nb_active - 1) ? 1u : 0u;
-    __syncthreads();
-    if (!s_last) return;
-    // last workgroup of this pass: pick the digit that holds the krem-th smallest candidate
-    __threadfence();
-    uint32_t krem_now = krem;
-    if (pass > 0) {
-        // winners appended during this pass are exactly those below the previous digit
-        krem_now = job.k - __hip_atomic_load(&ctl[SEL_NWIN], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    const uint32_t nkept = (pass == 0) ? M : __hip_atomic_load(&ctl[SEL_NOUT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (uint32_t i = threadIdx.x; i < MG_SEL_BINS; i += MG_BLOCK)
-        hist[i] = __hip_atomic_load(&job.hist[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    // parallel search of the bin where the running count crosses krem_now: 8 bins per thread
-    __shared__ uint32_t s_scan[8];
-    __shared__ uint32_t s_dstar;
-    if (threadIdx.x == 0) s_dstar = 0xFFFFFFFFu;
-    const uint32_t nbins = 1u << ncur;
-    constexpr uint32_t BPT = MG_SEL_BINS / MG_BLOCK;
-    uint32_t loc[BPT], lsum = 0;
+        // winners appended so far are exactly the keys below every decided digit
+        const uint32_t krem_now = job.k - nwin_total;
+        // parallel search of the bin where the running count crosses krem_now: 8 bins per thread
+        const uint32_t nbins = 1u << ncur;
+        constexpr uint32_t BPT = MG_SEL_BINS / MG_BLOCK;
+        uint32_t loc[BPT], lsum = 0;
 #pragma unroll
-    for (uint32_t j = 0; j < BPT; j++) { loc[j] = hist[threadIdx.x * BPT + j]; lsum += loc[j]; }
-    uint32_t tot;
-    const uint32_t excl = block_excl_scan(lsum, &tot, s_scan);
-    if (excl < krem_now && excl + lsum >= krem_now) {
-        uint32_t acc = excl;
+        for (uint32_t j = 0; j < BPT; j++) { loc[j] = hist[threadIdx.x * BPT + j]; lsum += loc[j]; }
+        uint32_t tot;
+        const uint32_t excl = block_excl_scan(lsum, &tot, s_scan);
+        if (excl < krem_now && excl + lsum >= krem_now) {
+            uint32_t acc = excl;
 #pragma unroll
-        for (uint32_t j = 0; j < BPT; j++) {
-            if (acc < krem_now && acc + loc[j] >= krem_now) s_dstar = threadIdx.x * BPT + j;
-            acc += loc[j];
+            for (uint32_t j = 0; j < BPT; j++) {
+                if (acc < krem_now && acc + loc[j] >= krem_now) { s_dstar = threadIdx.x * BPT + j; s_cum = acc + loc[j]; }
+                acc += loc[j];
+            }
         }
+        __syncthreads();
+        bool done = false, go_on = false;
+        {
+            uint32_t d = s_dstar, cum = s_cum;
+            if (d >= nbins) { d = nbins - 1; cum = nkept; }
+            // the final workgroup streams the kept list and sorts what passes the last decision
+            if (pass > 0 && nkept <= MG_SEL_FINAL) done = true;
+            else if (nkept <= SEL_SOLO_CHUNKS * SEL_CHUNK && nwin_total + cum <= MG_SEL_FINAL) done = true;
+            go_on = !done && sel_nblocks(nkept, gridDim.x) == 1;
+            if (threadIdx.x == 0) {
+                ctl[SEL_DSTAR] = d;
+                ctl[SEL_BPREV] = bitpos;
+                ctl[SEL_BITPOS] = next_bitpos;
+                ctl[SEL_KREM] = krem_now;
+                ctl[SEL_NIN] = nkept;
+                ctl[SEL_NWIN] = nwin_total;
+                ctl[SEL_NOUT] = 0;
+                ctl[SEL_TICKET] = 0;
+                ctl[SEL_NPREV] = (uint32_t)ncur;
+                ctl[SEL_NFIN] = nwin_total + cum;
+                if (pass >= 1) ctl[SEL_BUF] = buf ^ (pass == 1 ? 0u : 1u);
+                ctl[SEL_PASS] = pass + 1;
+                if (done) ctl[SEL_DONE] = 1;
+            }
+        }
+        if (!go_on) return;
+        // next pass in this launch: make this pass's list and control words visible to the whole workgroup
+        __threadfence();
+        continuing = true; vbid = 0;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t d = s_dstar;
-        if (d >= nbins) d = nbins - 1;
-        ctl[SEL_DSTAR] = d;
-        ctl[SEL_BPREV] = bitpos;
-        ctl[SEL_BITPOS] = next_bitpos;
-        ctl[SEL_KREM] = krem_now;
-        ctl[SEL_NIN] = nkept;
-        ctl[SEL_NOUT] = 0;
-        ctl[SEL_TICKET] = 0;
-        ctl[SEL_NPREV] = (uint32_t)ncur;
-        if (pass >= 1) ctl[SEL_BUF] = buf ^ (pass == 1 ? 0u : 1u);
-        ctl[SEL_PASS] = pass + 1;
-        // the list the final kernel reads is small enough once a pass kept <= MG_SEL_FINAL
-        if (pass > 0 && nkept <= MG_SEL_FINAL) ctl[SEL_DONE] = 1;
-    }
-    for (uint32_t i = threadIdx.x; i < MG_SEL_BINS; i += MG_BLOCK) job.hist[i] = 0;
 }
 
 struct SelOut { u64 *out_hi, *out_lo; uint32_t *out_pl; const uint32_t *payload; };
 
-// final stage: one workgroup per job sorts winners + remaining candidates and emits the top k
+// final stage: one workgroup per job sorts winners + remaining candidates and emits the top k.
+// Two sizes of the same kernel: jobs whose final set fits SEL_SMALL_CAP use a 10 KiB LDS variant
+// (many per CU), the rest the SEL_BIG_CAP one.
+template <int CAP, int LO>
 __global__ __launch_bounds__(MG_BLOCK) void k_select_final(const SelJob *jobs, const SelOut *outs) {
     const SelJob job = jobs[blockIdx.x];
     const SelOut out = outs[blockIdx.x];
     const uint32_t *ctl = job.ctl;
     const uint32_t M = *job.m_ptr;
-    constexpr int CAP = 2 * MG_SEL_FINAL;
     __shared__ u64 s_hi[CAP];
     __shared__ u64 s_lo[CAP];
     __shared__ uint32_t s_ix[CAP];
     __shared__ uint32_t s_n;
-    if (!ctl[SEL_DONE]) { if (threadIdx.x == 0) *job.out_n = 0xFFFFFFFFu; return; }   // host launches more passes
+    if (!ctl[SEL_DONE]) { if (LO == 0 && threadIdx.x == 0) *job.out_n = 0xFFFFFFFFu; return; }   // host launches more passes
+    const uint32_t nfin = ctl[SEL_NFIN];
+    if (nfin > (uint32_t)CAP || nfin < (uint32_t)LO) return;     // the other variant's job
     const uint32_t pass = ctl[SEL_PASS];
     const uint32_t nin = ctl[SEL_NIN];
     const uint32_t nwin = ctl[SEL_NWIN];
@@ -710,7 +781,7 @@ __global__ __launch_bounds__(MG_BLOCK) void k_select_final(const SelJob *jobs, c
     for (uint32_t i = threadIdx.x; i < nwin; i += MG_BLOCK) {
         const uint32_t idx = job.out_idx[i];
         const uint32_t p = atomicAdd(&s_n, 1u);
-        s_hi[p] = job.key_hi[idx]; s_lo[p] = job.key_lo[idx]; s_ix[p] = idx;
+        if (p < CAP) { s_hi[p] = job.key_hi[idx]; s_lo[p] = job.key_lo[idx]; s_ix[p] = idx; }
     }
     // the last candidate list, with the last decision applied
     for (uint32_t i = threadIdx.x; i < nin; i += MG_BLOCK) {
@@ -807,10 +878,16 @@ void mgk_card(hipStream_t st, const void *jobs, uint32_t njobs, uint32_t max_n) 
 }
 void mgk_select(hipStream_t st, const SelJob *jobs, const void *outs, uint32_t njobs, uint32_t max_m, int passes) {
     if (!njobs) return;
-    uint32_t gx = (max_m + MG_BLOCK * SEL_ITEMS - 1) / (MG_BLOCK * SEL_ITEMS); if (!gx) gx = 1;
+    // enough workgroups to fill the chip, never one per chunk of the largest possible list:
+    // workgroups stride over chunks, and most jobs end up in a single workgroup anyway
+    uint32_t gx = (max_m + SEL_CHUNK - 1) / SEL_CHUNK;
+    uint32_t cap = 4096 / njobs; if (cap < 1) cap = 1;
+    if (cap < 4) cap = 4;
+    if (gx <= SEL_SOLO_CHUNKS) gx = 1; else if (gx > cap) gx = cap;
     for (int p = 0; p < passes; p++)
         hipLaunchKernelGGL(k_select_pass, dim3(gx, njobs), dim3(MG_BLOCK), 0, st, jobs);
-    hipLaunchKernelGGL(k_select_final, dim3(njobs), dim3(MG_BLOCK), 0, st, jobs, (const SelOut *)outs);
+    hipLaunchKernelGGL((k_select_final<SEL_SMALL_CAP, 0>), dim3(njobs), dim3(MG_BLOCK), 0, st, jobs, (const SelOut *)outs);
+    hipLaunchKernelGGL((k_select_final<SEL_BIG_CAP, SEL_SMALL_CAP + 1>), dim3(njobs), dim3(MG_BLOCK), 0, st, jobs, (const SelOut *)outs);
 }
 void mgk_row_op(hipStream_t st, const unsigned long long *a, const unsigned long long *b, unsigned long long *out,
                 uint32_t W, int op, unsigned long long *card) {

@@ -9,7 +9,8 @@
 #define MG_PCAP         24           // in-register (slot,position) pairs per document before overflow
 #define MG_SEL_BINS     2048         // radix-select digit = 11 bits
 #define MG_SEL_DIGIT    11
-#define MG_SEL_PASSES   6            // fixed number of launched select passes (66 varying bits)
+#define MG_SEL_PASSES   3            // select passes launched per round (lists <= 32768 finish inside one launch)
+#define MG_SEL_SMALL    512          // final sets up to this size use the small sort workgroup
 #define MG_SEL_FINAL    2048         // candidates sorted by the final block
 #define MG_SCATTER_CHUNK 2048        // docids per scatter work item
 #define MG_LDS_HASH     4096         // wid table slots staged in LDS (32 KiB)

@@ -134,6 +134,30 @@ class GpuEngine:
             raise GpuError("msq_execute_batch: %d %s" % (rc, self.lib.mgpu_last_error().decode()))
         return outs
 
+    def prepare(self, pqs, capture=0):
+        """term lookups + filter leaf resolution for a batch; returns a handle for execute_prepared.
+        The parsed queries must stay alive as long as the handle."""
+        ns = self.index.num_shards
+        nq = len(pqs)
+        qarr = (C.POINTER(ffi.Query) * nq)(*[p.q for p in pqs])
+        h = C.c_void_p()
+        rc = self.lib.msq_prepare_batch(self._marr, ns, qarr, nq, capture, C.byref(h))
+        if rc:
+            raise GpuError("msq_prepare_batch: %d %s" % (rc, self.lib.mgpu_last_error().decode()))
+        return (h, nq, pqs)
+
+    def execute_prepared(self, prep):
+        h, nq, _ = prep
+        outs = (ffi.SqResult * (nq * self.index.num_shards))()
+        rc = self.lib.msq_execute_prepared(self.ctx, h, outs)
+        if rc:
+            self.free_raw(outs)
+            raise GpuError("msq_execute_prepared: %d %s" % (rc, self.lib.mgpu_last_error().decode()))
+        return outs
+
+    def free_prepared(self, prep):
+        self.lib.msq_prepared_free(prep[0])
+
     def free_raw(self, outs):
         for i in range(len(outs)):
             self.lib.m_sqresult_free(C.byref(outs[i]))

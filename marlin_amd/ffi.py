@@ -156,6 +156,9 @@ def load():
         "m_form_result_batch": (C.c_long, [C.POINTER(C.POINTER(Query)), C.POINTER(SqResult), ci, ci, C.POINTER(Result), ci]),
         "mmirror_gpu": (vp, [vp]),
         "msq_execute_batch": (ci, [vp, C.POINTER(vp), ci, C.POINTER(C.POINTER(Query)), ci, ci, C.POINTER(SqResult)]),
+        "msq_prepare_batch": (ci, [C.POINTER(vp), ci, C.POINTER(C.POINTER(Query)), ci, ci, C.POINTER(vp)]),
+        "msq_execute_prepared": (ci, [vp, vp, C.POINTER(SqResult)]),
+        "msq_prepared_free": (None, [vp]),
         # GPU C ABI (include/marlin_gpu.h), reached through the same process image
         "mgpu_last_error": (C.c_char_p, []),
         "mgpu_device_count": (ci, []),

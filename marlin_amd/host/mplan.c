@@ -323,34 +323,72 @@ static void *plan_worker(void *arg) {
 }
 
 mgpu_shard_t *mmirror_gpu(mmirror_t *m) { return m ? m->g : NULL; }
+
+struct msq_prepared {
+    int n, nq, num_shards;
+    mmirror_t *const *mirrors; const m_query_t **queries;
+    mplan_t *plans; mgpu_plan_t *gp; mgpu_shard_t **gs;
+};
+
+/* lookup_terms (squery.c:144-167) + filter leaf resolution for every (query, shard) pair */
+int msq_prepare_batch(mmirror_t *const *mirrors, int num_shards, const m_query_t *const *queries,
+                      int nq, int capture, msq_prepared_t **out) {
+    int n = nq * num_shards;
+    msq_prepared_t *pp = calloc(1, sizeof(*pp));
+    pp->n = n; pp->nq = nq; pp->num_shards = num_shards; pp->mirrors = mirrors;
+    pp->queries = calloc((size_t)(nq ? nq : 1), sizeof(*pp->queries));
+    memcpy(pp->queries, queries, (size_t)nq * sizeof(*pp->queries));
+    pp->plans = calloc((size_t)(n ? n : 1), sizeof(mplan_t));
+    pp->gp = calloc((size_t)(n ? n : 1), sizeof(mgpu_plan_t));
+    pp->gs = calloc((size_t)(n ? n : 1), sizeof(mgpu_shard_t *));
+    int rc = 0;
+    int nthreads = msq_plan_threads;
+    if (nthreads > n) nthreads = n;
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 64) nthreads = 64;
+    struct plan_job jobs[64];
+    pthread_t th[64];
+    for (int t = 0; t < nthreads; t++) {
+        jobs[t].mirrors = mirrors; jobs[t].num_shards = num_shards; jobs[t].queries = queries;
+        jobs[t].capture = capture; jobs[t].plans = pp->plans; jobs[t].gp = pp->gp; jobs[t].gs = pp->gs;
+        jobs[t].lo = (int)((long)n * t / nthreads); jobs[t].hi = (int)((long)n * (t + 1) / nthreads); jobs[t].rc = 0;
+    }
+    if (nthreads == 1) plan_worker(&jobs[0]);
+    else {
+        for (int t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, plan_worker, &jobs[t]);
+        for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+    }
+    for (int t = 0; t < nthreads; t++) if (jobs[t].rc) rc = jobs[t].rc;
+    if (rc) { msq_prepared_free(pp); pp = NULL; }
+    *out = pp;
+    return rc;
+}
+
+void msq_prepared_free(msq_prepared_t *pp) {
+    if (!pp) return;
+    for (int i = 0; i < pp->n; i++) mplan_free(&pp->plans[i]);
+    free(pp->plans); free(pp->gp); free(pp->gs); free(pp->queries); free(pp);
+}
+
 int msq_execute_batch(mgpu_ctx_t *ctx, mmirror_t *const *mirrors, int num_shards,
                       const m_query_t *const *queries, int nq, int capture, m_sqresult_t *outs) {
-    int n = nq * num_shards;
-    mplan_t *plans = calloc((size_t)n, sizeof(mplan_t));
-    mgpu_plan_t *gp = calloc((size_t)n, sizeof(mgpu_plan_t));
-    mgpu_shard_t **gs = calloc((size_t)n, sizeof(mgpu_shard_t *));
-    mgpu_sqout_t *go = calloc((size_t)n, sizeof(mgpu_sqout_t));
+    msq_prepared_t *pp = NULL;
+    int rc = msq_prepare_batch(mirrors, num_shards, queries, nq, capture, &pp);
+    if (rc) { memset(outs, 0, sizeof(*outs) * (size_t)nq * (size_t)num_shards); return rc; }
+    rc = msq_execute_prepared(ctx, pp, outs);
+    msq_prepared_free(pp);
+    return rc;
+}
+
+/* the part of execute_squery after lookup_terms: bitmap formula, filter, ranking, facets, aggs,
+ * top-2N (squery.c:480-536) as one GPU batch */
+int msq_execute_prepared(mgpu_ctx_t *ctx, const msq_prepared_t *pp, m_sqresult_t *outs) {
+    int n = pp->n, num_shards = pp->num_shards;
+    mmirror_t *const *mirrors = pp->mirrors;
+    const m_query_t *const *queries = (const m_query_t *const *)pp->queries;
+    mgpu_plan_t *gp = pp->gp; mgpu_shard_t **gs = pp->gs;
+    mgpu_sqout_t *go = calloc((size_t)(n ? n : 1), sizeof(mgpu_sqout_t));
     int rc = 0;
-    {
-        /* lookup_terms for every (query, shard) pair: independent, so spread over host threads */
-        int nthreads = msq_plan_threads;
-        if (nthreads > n) nthreads = n;
-        if (nthreads < 1) nthreads = 1;
-        struct plan_job jobs[64];
-        pthread_t th[64];
-        if (nthreads > 64) nthreads = 64;
-        for (int t = 0; t < nthreads; t++) {
-            jobs[t].mirrors = mirrors; jobs[t].num_shards = num_shards; jobs[t].queries = queries;
-            jobs[t].capture = capture; jobs[t].plans = plans; jobs[t].gp = gp; jobs[t].gs = gs;
-            jobs[t].lo = (int)((long)n * t / nthreads); jobs[t].hi = (int)((long)n * (t + 1) / nthreads); jobs[t].rc = 0;
-        }
-        if (nthreads == 1) plan_worker(&jobs[0]);
-        else {
-            for (int t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, plan_worker, &jobs[t]);
-            for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
-        }
-        for (int t = 0; t < nthreads; t++) if (jobs[t].rc) rc = jobs[t].rc;
-    }
     if (!rc) rc = mgpu_execute(ctx, gs, gp, n, go);
     for (int i = 0; i < n; i++) {
         const m_query_t *q = queries[i / num_shards];
@@ -399,7 +437,7 @@ int msq_execute_batch(mgpu_ctx_t *ctx, mmirror_t *const *mirrors, int num_shards
         o->dbg_docid_map = g->dbg_docid_map; o->dbg_words = g->dbg_words; g->dbg_docid_map = NULL;
         o->dbg_all_ranks = (m_docrank_t *)g->dbg_all_ranks; g->dbg_all_ranks = NULL;
     }
-    for (int i = 0; i < n; i++) { mgpu_sqout_free(&go[i]); mplan_free(&plans[i]); }
-    free(plans); free(gp); free(gs); free(go);
+    for (int i = 0; i < n; i++) mgpu_sqout_free(&go[i]);
+    free(go);
     return rc;
 }

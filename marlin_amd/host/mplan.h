@@ -53,6 +53,15 @@ void mplan_free(mplan_t *pl);
 int  msq_execute_batch(mgpu_ctx_t *ctx, mmirror_t *const *mirrors, int num_shards,
                        const m_query_t *const *queries, int nq, int capture, m_sqresult_t *outs);
 
+/* The same in two halves, so a caller can keep the term lookups (dtrie walk; not part of the
+ * GPU hot path) apart from the batch execution: prepare = lookup_terms + filter leaf
+ * resolution for every (query, shard); execute_prepared = everything after it. */
+typedef struct msq_prepared msq_prepared_t;
+int  msq_prepare_batch(mmirror_t *const *mirrors, int num_shards, const m_query_t *const *queries,
+                       int nq, int capture, msq_prepared_t **out);
+int  msq_execute_prepared(mgpu_ctx_t *ctx, const msq_prepared_t *pp, m_sqresult_t *outs);
+void msq_prepared_free(msq_prepared_t *pp);
+
 /* host threads used for plan building inside msq_execute_batch (default 1) */
 void msq_set_plan_threads(int n);
 mgpu_shard_t *mmirror_gpu(mmirror_t *m);

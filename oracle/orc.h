@@ -56,6 +56,9 @@ void     orc_bm_andnot(uint64_t *dst, const uint64_t *src, size_t words);
 uint64_t orc_bm_cardinality(const uint64_t *a, size_t words);
 void     orc_bm_from_list(uint64_t *dst, const uint32_t *docs, uint64_t n);
 
+/* seconds spent inside mdict_lookup_term / mdict_lookup_exact since the last reset (not thread safe) */
+double orc_lookup_time(int reset);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,6 +23,8 @@ def load():
         lib = C.CDLL(path)
         lib.orc_execute_squery.restype = C.c_int
         lib.orc_execute_squery.argtypes = [C.c_void_p, C.POINTER(ffi.Query), C.c_int, C.c_int, C.POINTER(ffi.SqResult)]
+        lib.orc_lookup_time.restype = C.c_double
+        lib.orc_lookup_time.argtypes = [C.c_int]
         _lib = lib
     return _lib
 
@@ -35,6 +37,11 @@ def execute_raw(index, pq, flags=0):
         if rc:
             raise RuntimeError("orc_execute_squery: %d" % rc)
     return outs
+
+
+def lookup_time(reset=False):
+    """seconds the oracle spent in dictionary lookups since the last reset"""
+    return load().orc_lookup_time(1 if reset else 0)
 
 
 def search(index, pq, flags=0):

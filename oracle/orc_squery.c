@@ -5,6 +5,13 @@
 #include <stdlib.h>
 #include <string.h>
 #include <float.h>
+#include <time.h>
+
+/* seconds spent in the dictionary (trie) lookups since the last reset: lets bench.py report the
+ * CPU baseline with and without the term lookup, which the GPU path keeps on the host too */
+double orc_lookup_seconds = 0.0;
+static double orc_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
+double orc_lookup_time(int reset) { double v = orc_lookup_seconds; if (reset) orc_lookup_seconds = 0.0; return v; }
 
 /* ------------------------------------------------------------------ dense bitmaps */
 void orc_bm_or(uint64_t *d, const uint64_t *s, size_t w) { for (size_t i = 0; i < w; i++) d[i] |= s[i]; }
@@ -146,11 +153,15 @@ static void process_termresult(ctx_t *c, int t) {
 /* lookup_terms (squery.c:144-167) */
 static void lookup_terms(ctx_t *c) {
     for (int i = 0; i < c->num_terms; i++) {
+        double t0 = orc_now();
         mdict_lookup_term(c->s->dict, &c->q->terms[i], &c->tr[i]);
+        orc_lookup_seconds += orc_now() - t0;
         process_termresult(c, i);
     }
     for (int i = 0; i < c->q->num_words; i++) {
+        double t0 = orc_now();
         uint32_t wid = mdict_lookup_exact(c->s->dict, &c->q->words[i]);
+        orc_lookup_seconds += orc_now() - t0;
         c->exact_docs[i] = NULL; c->exact_n[i] = 0;
         if (wid) c->exact_n[i] = mshard_wid_posting(c->s, wid, &c->exact_docs[i]);
     }
