@@ -16,10 +16,13 @@ typedef unsigned long long u64;
 
 extern "C" {
 void mgk_scatter(hipStream_t st, const ScatterItem *items, uint32_t nitems);
-void mgk_formula(hipStream_t st, const SqDev *sqs, const uint32_t *blob, uint32_t max_nblk, uint32_t nsq);
+void mgk_formula(hipStream_t st, const SqDev *sqs, const uint32_t *blob, uint32_t max_nblk, uint32_t nsq,
+                 uint2 *tile_list, uint32_t *tile_count);
 void mgk_rank(hipStream_t st, const SqDev *sqs, const uint32_t *blob, uint32_t max_n, uint32_t nsq,
+              uint32_t max_tab_slots, const uint2 *tile_list, const uint32_t *tile_count, uint32_t tile_cap,
               unsigned long long *pool, uint32_t *pool_used, uint64_t pool_cap);
-void mgk_docproc(hipStream_t st, const SqDev *sqs, uint32_t max_pblocks, uint32_t nsq);
+void mgk_docproc(hipStream_t st, const SqDev *sqs, uint32_t nsq, const uint2 *tile_list, const uint32_t *tile_count,
+                 uint32_t tile_cap);
 void mgk_fkeys(hipStream_t st, const void *jobs, uint32_t njobs, uint32_t max_n);
 void mgk_card(hipStream_t st, const void *jobs, uint32_t njobs, uint32_t max_n);
 void mgk_select(hipStream_t st, const SelJob *jobs, const void *outs, uint32_t njobs, uint32_t max_m, int passes);
@@ -27,9 +30,9 @@ void mgk_row_op(hipStream_t st, const unsigned long long *a, const unsigned long
                 uint32_t W, int op, unsigned long long *card);
 }
 
-struct FkJob { const uint32_t *hist; const uint32_t *ord2id; uint32_t n; uint32_t pad; u64 *key_hi, *key_lo;
-               uint32_t *nnz; u64 *andor; };
-struct CardJob { const uint32_t *hist; const uint32_t *ord2id; uint32_t n; uint32_t pad; uint32_t *out_ids; uint32_t *out_n; };
+struct FkJob { const uint32_t *hist; const uint32_t *ord2id; const uint32_t *touched; const uint32_t *ntouched;
+               u64 *key_hi, *key_lo; u64 *andor; };
+struct CardJob { const uint32_t *ord2id; const uint32_t *touched; const uint32_t *ntouched; uint32_t *out_ids; uint32_t *out_n; };
 struct SelOut { u64 *out_hi, *out_lo; uint32_t *out_pl; const uint32_t *payload; };
 
 static thread_local std::string g_err;
@@ -405,14 +408,14 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
     Bump zer;          // rest of the zero region
     Bump nz;           // non-zero region
     std::vector<int> nrows(n, 0);
-    uint32_t max_nblk = 1, max_N = 1, max_pblocks = 1, max_fk = 1, max_selm = 1;
+    uint32_t max_nblk = 1, max_N = 1, max_pblocks = 1, max_fk = 1, max_selm = 1, max_tab = 1;
 
     struct Offs {      // arena offsets per squery (zero or nonzero region relative)
-        size_t rows, hist[MGPU_MAX_FIELDS], andor, ovfcnt, docmap, blk, hits, khi, klo, ovfl, aggpart;
+        size_t rows, hist[MGPU_MAX_FIELDS], touched[MGPU_MAX_FIELDS], ntouched[MGPU_MAX_FIELDS], andor, ovfcnt, docmap, blk, hits, khi, klo, ovfl, aggpart;
         size_t fkhi[MGPU_MAX_FIELDS], fklo[MGPU_MAX_FIELDS];
     };
     std::vector<Offs> offs(n);
-    struct SelOff { size_t cand0, cand1, hist, ctl, outidx, nnz, andor; uint32_t mcap; };
+    struct SelOff { size_t cand0, cand1, hist, ctl, outidx, andor; uint32_t mcap; };
     std::vector<SelOff> seloff;
 
     for (int i = 0; i < n; i++) {
@@ -515,7 +518,9 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
         // wid table
         {
             uint32_t cap = 2; while (cap < 2 * p.num_wids + 2) cap <<= 1;
+            if (blob.size() & 1) blob.push_back(0);          // 8-byte aligned slots
             q.hash_off = (uint32_t)blob.size(); q.hash_mask = cap - 1;
+            if (cap <= MG_LDS_HASH) max_tab = std::max(max_tab, cap);
             size_t base = blob.size();
             blob.resize(base + (size_t)cap * 2, 0);
             for (uint32_t j = 0; j < p.num_wids; j++) {
@@ -575,7 +580,11 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
             }
         }
         o.rows = 0;   // filled after nrows is final (below)
-        for (int f = 0; f < sd.num_facets; f++) if ((hmask >> f) & 1u) o.hist[f] = zer.take((size_t)sd.fa_nord[f] * 4 + 4);
+        for (int f = 0; f < sd.num_facets; f++) if ((hmask >> f) & 1u) {
+            o.hist[f] = zer.take((size_t)sd.fa_nord[f] * 4 + 4);
+            o.ntouched[f] = zer.take(4, 4);
+            o.touched[f] = nz.take((size_t)sd.fa_nord[f] * 4 + 4);
+        }
         o.andor = zer.take(32); o.ovfcnt = zer.take(4);
         o.docmap = nz.take((size_t)sd.Wp * 8); o.blk = nz.take((size_t)(q.nblk + 1) * 4);
         o.hits = nz.take((size_t)sd.N * 4);
@@ -611,11 +620,17 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
             SelOff so; so.mcap = sd.fa_nord[f];
             so.cand0 = nz.take((size_t)so.mcap * 4); so.cand1 = nz.take((size_t)so.mcap * 4);
             so.hist = zer.take(MG_SEL_BINS * 4); so.ctl = zer.take(SEL_WORDS * 4); so.outidx = nz.take((size_t)MG_SEL_FINAL * 4);
-            so.nnz = zer.take(4, 4); so.andor = zer.take(32, 8);
+            so.andor = zer.take(32, 8);
             seloff.push_back(so); jobfix.push_back({i, 1, j});
             max_selm = std::max(max_selm, so.mcap);
         }
     }
+    // batch-wide work list of hit tiles, filled by k_scan
+    size_t tile_cap = 0;
+    for (int i = 0; i < n; i++) tile_cap += ((size_t)sqd[i].sh.N + MG_BLOCK - 1) / MG_BLOCK;
+    if (tile_cap > 0xFFFFFFFFull) return fail(MGPU_E_LIMIT, "batch too large for the tile work list");
+    const size_t off_tilecnt = zer.take(4, 4);
+    const size_t off_tiles = nz.take(std::max<size_t>(tile_cap, 1) * sizeof(uint2));
     // scratch rows (zero region), now that row counts are known
     for (int i = 0; i < n; i++) offs[i].rows = zer.take((size_t)std::max(nrows[i], 1) * sqd[i].sh.Wp * 8);
 
@@ -665,7 +680,11 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
         q.key_hi = (uint64_t *)(NZ + o.khi); q.key_lo = (uint64_t *)(NZ + o.klo);
         q.key_andor = (uint64_t *)(Z + o.andor);
         q.ovf_list = (uint32_t *)(NZ + o.ovfl);
-        for (int f = 0; f < q.sh.num_facets; f++) if ((q.hist_mask >> f) & 1u) q.hist[f] = (uint32_t *)(Z + o.hist[f]);
+        for (int f = 0; f < q.sh.num_facets; f++) if ((q.hist_mask >> f) & 1u) {
+            q.hist[f] = (uint32_t *)(Z + o.hist[f]);
+            q.ntouched[f] = (uint32_t *)(Z + o.ntouched[f]);
+            q.touched[f] = (uint32_t *)(NZ + o.touched[f]);
+        }
         q.agg_part = (AggPart *)(NZ + o.aggpart);
         q.agg_out = hdr->agg;
         h.docid_map_off = nz_base + o.docmap; h.hits_off = nz_base + o.hits;
@@ -700,13 +719,13 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
             Offs &o = offs[jf.sq];
             q.fkey_hi[f] = (uint64_t *)(NZ + o.fkhi[f]); q.fkey_lo[f] = (uint64_t *)(NZ + o.fklo[f]);
             sj.key_hi = q.fkey_hi[f]; sj.key_lo = q.fkey_lo[f];
-            sj.m_ptr = (const uint32_t *)(Z + so.nnz);
+            sj.m_ptr = q.ntouched[f];
             sj.k = h.fac_k[jf.field]; sj.out_n = &hdr->fac_n[jf.field]; sj.mask = (const uint64_t *)(Z + so.andor); sj.skip_ones = 1;
             so2.out_hi = (u64 *)(R + h.fac_hi[jf.field]); so2.out_lo = (u64 *)(R + h.fac_lo[jf.field]);
             so2.out_pl = (uint32_t *)(R + h.fac_pl[jf.field]); so2.payload = nullptr;
-            FkJob fj; fj.hist = q.hist[f]; fj.ord2id = q.sh.fa_ord2id[f]; fj.n = q.sh.fa_nord[f]; fj.pad = 0;
+            FkJob fj; fj.hist = q.hist[f]; fj.ord2id = q.sh.fa_ord2id[f]; fj.touched = q.touched[f]; fj.ntouched = q.ntouched[f];
             fj.key_hi = (u64 *)q.fkey_hi[f]; fj.key_lo = (u64 *)q.fkey_lo[f];
-            fj.nnz = (uint32_t *)(Z + so.nnz); fj.andor = (u64 *)(Z + so.andor);
+            fj.andor = (u64 *)(Z + so.andor);
             fkjobs.push_back(fj);
         }
     }
@@ -715,7 +734,7 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
         ResHdr *hdr = (ResHdr *)(R + h.hdr_off);
         for (int j = 0; j < h.ncard; j++) {
             int f = q.agg_field[h.card_agg[j]];
-            CardJob cj; cj.hist = q.hist[f]; cj.ord2id = q.sh.fa_ord2id[f]; cj.n = q.sh.fa_nord[f]; cj.pad = 0;
+            CardJob cj; cj.ord2id = q.sh.fa_ord2id[f]; cj.touched = q.touched[f]; cj.ntouched = q.ntouched[f];
             cj.out_ids = (uint32_t *)(A + nz_base + h.card_ids_off[j]); cj.out_n = &hdr->card_n[j];
             cardjobs.push_back(cj);
         }
@@ -746,11 +765,12 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
     mark();
     mgk_scatter(st, (const ScatterItem *)(UP + up_items), (uint32_t)items.size());
     mark();
-    mgk_formula(st, d_sq, d_blob, max_nblk, (uint32_t)n);
+    uint2 *d_tiles = (uint2 *)(NZ + off_tiles); uint32_t *d_tilecnt = (uint32_t *)(Z + off_tilecnt);
+    mgk_formula(st, d_sq, d_blob, max_nblk, (uint32_t)n, d_tiles, d_tilecnt);
     mark();
-    mgk_rank(st, d_sq, d_blob, max_N, (uint32_t)n, c->pool, c->pool_used, c->pool_cap);
+    mgk_rank(st, d_sq, d_blob, max_N, (uint32_t)n, max_tab, d_tiles, d_tilecnt, (uint32_t)tile_cap, c->pool, c->pool_used, c->pool_cap);
     mark();
-    mgk_docproc(st, d_sq, max_pblocks, (uint32_t)n);
+    mgk_docproc(st, d_sq, (uint32_t)n, d_tiles, d_tilecnt, (uint32_t)tile_cap);
     mark();
     mgk_fkeys(st, UP + up_fk, (uint32_t)fkjobs.size(), max_fk);
     mgk_card(st, UP + up_card, (uint32_t)cardjobs.size(), max_fk);
@@ -859,7 +879,12 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
             per += na * (4 + 8);
             c->stage_bytes[4] += (uint64_t)(M * per);
         }
-        for (int j = 0; j < h.nfac; j++) c->stage_bytes[5] += (uint64_t)q.sh.fa_nord[h.fac_field[j]] * 24;
+        for (int j = 0; j < h.nfac; j++) {
+            // touched bins (at most one per facet value of a hit): bin index + count + id in, 16-byte key out
+            const int f = h.fac_field[j];
+            const double touched = std::min<double>((double)q.sh.fa_nord[f], (double)M * sh->avg_fv[f]);
+            c->stage_bytes[5] += (uint64_t)(touched * 28.0);
+        }
         if (h.k) c->stage_bytes[6] += 16 * M * (M > MG_SEL_SMALL ? 2 : 1);
     }
     c->stage_bytes[0] = up_bytes; c->stage_bytes[7] = res_bytes;

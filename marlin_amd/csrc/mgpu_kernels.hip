@@ -4,6 +4,7 @@
 // u64 bitmap rows, wave-level popcount / ballot compaction, LDS-privatised histograms and an
 // LDS bitonic stage for the final top-k.  No MFMA: nothing here is a dense contraction.
 // blockIdx.y always selects the (shard, query) pair ("squery") of a batch.
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include "mgpu_types.h"
 
@@ -137,10 +138,13 @@ __global__ __launch_bounds__(MG_BLOCK) void k_formula(const SqDev *sqs, const ui
 }
 
 // exclusive scan of the per-block hit counts; one workgroup per squery
-__global__ __launch_bounds__(MG_BLOCK) void k_scan(const SqDev *sqs) {
+// Also publishes the squery's hit tiles (256 hits each) on the batch-wide work list that the
+// rank and facet/agg kernels stride over: their grids never depend on a host-side guess of
+// the hit count, and a batch of uneven queries balances itself.
+__global__ __launch_bounds__(MG_BLOCK) void k_scan(const SqDev *sqs, uint2 *tile_list, uint32_t *tile_count) {
     const SqDev &sq = sqs[blockIdx.x];
     __shared__ uint32_t lds[8];
-    __shared__ uint32_t carry;
+    __shared__ uint32_t carry, s_base;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
     for (uint32_t base = 0; base < sq.nblk; base += MG_BLOCK) {
@@ -154,7 +158,11 @@ __global__ __launch_bounds__(MG_BLOCK) void k_scan(const SqDev *sqs) {
         if (threadIdx.x == 0) carry = c + tot;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *sq.num_hits = carry;
+    const uint32_t M = carry;
+    const uint32_t ntiles = (M + MG_BLOCK - 1) / MG_BLOCK;
+    if (threadIdx.x == 0) { *sq.num_hits = M; s_base = ntiles ? atomicAdd(tile_count, ntiles) : 0; }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < ntiles; i += MG_BLOCK) tile_list[s_base + i] = make_uint2(blockIdx.x, i);
 }
 
 // bmap_iterate / cont_iterate (bmap.c:370-374, cont.c:590-610): bitmap -> ascending docid list
@@ -181,22 +189,44 @@ __device__ __forceinline__ uint32_t hash_wid(uint32_t h) {
     h ^= h >> 16; h *= 0x7feb352dU; h ^= h >> 15; h *= 0x846ca68bU; h ^= h >> 16;
     return h;
 }
-
-// insertion sort of packed (slot << 32 | position) pairs
-__device__ __forceinline__ void sort_pairs(u64 *p, int n) {
-    for (int i = 1; i < n; i++) {
-        u64 x = p[i];
-        int j = i - 1;
-        while (j >= 0 && p[j] > x) { p[j + 1] = p[j]; j--; }
-        p[j + 1] = x;
+__device__ __forceinline__ bool probe_wid(const uint2 *htab, uint32_t hmask, uint32_t wid, uint32_t &val) {
+    for (uint32_t h = hash_wid(wid) & hmask;; h = (h + 1) & hmask) {
+        const uint2 s = htab[h];
+        if (s.x == wid) { val = s.y; return true; }
+        if (s.x == 0) return false;
     }
 }
 
-// the proximity walk of docrank.c:188-204 / 303-319 over two sorted runs inside p[]
-__device__ __forceinline__ int prox_walk(const u64 *p, int a0, int a1, int b0, int b1) {
+// (slot, position) pairs of one document, packed (slot << 24) | (priority << 16) | position.
+// Two homes: a lane-strided LDS slice (fast path) or a slice of the global pool (overflow path).
+struct LdsPairs {
+    uint32_t *base; int cap;
+    __device__ __forceinline__ uint32_t get(int j) const { return base[j * MG_BLOCK]; }
+    __device__ __forceinline__ void set(int j, uint32_t v) { base[j * MG_BLOCK] = v; }
+};
+struct PoolPairs {
+    uint32_t *base; int cap;
+    __device__ __forceinline__ uint32_t get(int j) const { return base[j]; }
+    __device__ __forceinline__ void set(int j, uint32_t v) { base[j] = v; }
+};
+
+// insertion sort: slot-major, then position
+template <class PS>
+__device__ __forceinline__ void sort_pairs(PS &p, int n) {
+    for (int i = 1; i < n; i++) {
+        const uint32_t x = p.get(i);
+        int j = i - 1;
+        while (j >= 0 && p.get(j) > x) { p.set(j + 1, p.get(j)); j--; }
+        p.set(j + 1, x);
+    }
+}
+
+// the proximity walk of docrank.c:188-204 / 303-319 over two sorted runs
+template <class PS>
+__device__ __forceinline__ int prox_walk(const PS &p, int a0, int a1, int b0, int b1) {
     int i = a0, j = b0, mindiff = 8;
     while (i < a1 && j < b1) {
-        int pos1 = (int)(uint32_t)p[i], pos2 = (int)(uint32_t)p[j];
+        const int pos1 = (int)(p.get(i) & 0xFFFFFFu), pos2 = (int)(p.get(j) & 0xFFFFFFu);
         int diff = pos1 - pos2; if (diff < 0) diff = -diff;
         if (diff != 0 && diff < mindiff) { mindiff = diff; if (mindiff == 1) break; }
         if (pos1 > pos2) j++; else i++;
@@ -204,127 +234,122 @@ __device__ __forceinline__ int prox_walk(const u64 *p, int a0, int a1, int b0, i
     return mindiff;
 }
 
-// calculate_rank (docrank.c:338-369) for one document.  `pairs`/`cap` is the position scratch
-// (registers/private memory on the fast path, a slice of the global pool on the overflow path).
-// Returns false when the scratch overflowed.
-__device__ bool rank_doc(const SqDev &sq, const uint2 *htab, uint32_t hmask, uint32_t docid,
-                         u64 *pairs, int cap, RankOut &ro) {
-    const int nw = sq.num_words, nt = sq.num_terms;
-    const uint32_t e0 = sq.sh.dw_off[docid], e1 = sq.sh.dw_off[docid + 1];
-    const uint32_t pbase = sq.sh.pp_off[docid];
-    uint32_t exact_mask = 0;
-    u64 single_best = ~0ull;            // (dist << 40) | (priority << 32) | position, single-word queries
-    u64 typ_lo = ~0ull, typ_hi = ~0ull; // per-word typos, one byte each (0xFF = unmatched)
-    uint32_t prox1 = 0;                 // bit x: word x matched through a concatenated (odd) term
-    bool comb = false;                  // the all-words term matched
-    uint32_t bestpos = 0xFFFFFFFFu;
-    int np = 0;
-    bool ovf = false;
+// calculate_rank (docrank.c:338-369) split in three: per-document state, one step per document
+// word that the query's wid table knows, and the final combination.  Every update commutes
+// (min, or, clear-to-zero, a set of pairs sorted later), so the words may arrive in any order.
+struct RankState {
+    u64 single_best;                    // (dist << 40) | (priority << 16) | position, single-word queries
+    u64 typ_lo, typ_hi;                 // per-word typos, one byte each (0xFF = unmatched)
+    uint32_t exact_mask;
+    uint32_t prox1;                     // bit x: word x matched through a concatenated (odd) term
+    uint32_t bestpos;
+    int np;
+    bool comb;                          // the all-words term matched
+    bool ovf;                           // the pair store overflowed
+};
+__device__ __forceinline__ void rank_init(RankState &s) {
+    s.single_best = ~0ull; s.typ_lo = ~0ull; s.typ_hi = ~0ull; s.exact_mask = 0; s.prox1 = 0;
+    s.bestpos = 0xFFFFFFFFu; s.np = 0; s.comb = false; s.ovf = false;
+}
 
-    for (uint32_t e = e0; e < e1; e++) {
-        const uint2 wi = sq.sh.dw[e];
-        uint32_t val = 0; bool found = false;
-        for (uint32_t h = hash_wid(wi.x) & hmask;; h = (h + 1) & hmask) {
-            const uint2 s = htab[h];
-            if (s.x == wi.x) { val = s.y; found = true; break; }
-            if (s.x == 0) break;
-        }
-        if (!found) continue;
-        exact_mask |= val >> 16;
-        const uint32_t dist = val & 0xFF, mterm = (val >> 8) & 0xFF;
-        if (dist == 0xFF) continue;
-        const bool inl = wi.y & 1u;
-        const uint32_t cnt = inl ? 1u : ((wi.y >> 1) & 0xFFu);
-        const uint32_t poff = wi.y >> 9;
-        const uint32_t first = inl ? ((((wi.y >> 1) & 0xFFu) << 16) + poff) : sq.sh.pp[pbase + poff];
-        if (nw == 1) {
-            // rank_single_term (docrank.c:63-112): least distance, then least (field, position)
-            u64 k = ((u64)dist << 40) | (u64)first;      // first = (priority << 16) + position of the best occurrence
-            if (k < single_best) single_best = k;
-            continue;
-        }
-        int slot_a, slot_b = -1;
-        if (nw == 2) {
-            // rank_three_terms (docrank.c:125-209)
-            if (mterm == 2) comb = true;
-            else {
-                const int sh8 = (int)mterm * 8;
-                if (dist < ((typ_lo >> sh8) & 0xFF)) typ_lo = (typ_lo & ~(0xFFull << sh8)) | ((u64)dist << sh8);
-            }
-            slot_a = (int)mterm;
-        } else {
-            // rank_many_terms (docrank.c:218-328); term_to_word_idx's quirk reduces to term / 2
-            if ((int)mterm == nt - 1) comb = true;
-            const int widx = (int)mterm >> 1;
-            {
-                u64 &tw = widx < 8 ? typ_lo : typ_hi;
-                const int sh8 = (widx & 7) * 8;
-                if (dist < ((tw >> sh8) & 0xFF)) tw = (tw & ~(0xFFull << sh8)) | ((u64)dist << sh8);
-            }
-            slot_a = widx;
-            if (mterm & 1u) {
-                prox1 |= 1u << widx;
-                if ((int)mterm != nt - 1) {
-                    const int w1 = widx + 1;
-                    u64 &tw = w1 < 8 ? typ_lo : typ_hi;
-                    tw &= ~(0xFFull << ((w1 & 7) * 8));
-                    slot_b = w1;
-                }
-            }
-        }
-        if (first < bestpos) bestpos = first;          // runs are sorted: the first entry is the least
-        const bool keep_a = !(nw == 2 && slot_a == 2); // the pair term only feeds best_position
-        for (uint32_t j = 0; j < cnt; j++) {
-            const uint32_t p = inl ? first : sq.sh.pp[pbase + poff + j];
-            if (keep_a) { if (np < cap) pairs[np++] = ((u64)slot_a << 32) | p; else ovf = true; }
-            if (slot_b >= 0) { if (np < cap) pairs[np++] = ((u64)slot_b << 32) | p; else ovf = true; }
-        }
-        if (ovf) return false;
+// val = dist | mterm << 8 | exact_mask << 16 (wid table); info = the docword's position descriptor;
+// pp_doc = the document's slice of the position pool
+template <class PS>
+__device__ __forceinline__ void rank_consume(RankState &s, int nw, int nt, uint32_t val, uint32_t info,
+                                             const uint32_t *pp_doc, PS &ps) {
+    s.exact_mask |= val >> 16;
+    const uint32_t dist = val & 0xFF, mterm = (val >> 8) & 0xFF;
+    if (dist == 0xFF) return;
+    const bool inl = info & 1u;
+    const uint32_t cnt = inl ? 1u : ((info >> 1) & 0xFFu);
+    const uint32_t poff = info >> 9;
+    const uint32_t first = inl ? ((((info >> 1) & 0xFFu) << 16) + poff) : pp_doc[poff];
+    if (nw == 1) {
+        // rank_single_term (docrank.c:63-112): least distance, then least (field, position)
+        const u64 k = ((u64)dist << 40) | (u64)first;
+        if (k < s.single_best) s.single_best = k;
+        return;
     }
+    int slot_a, slot_b = -1;
+    if (nw == 2) {
+        // rank_three_terms (docrank.c:125-209)
+        if (mterm == 2) s.comb = true;
+        else {
+            const int sh8 = (int)mterm * 8;
+            if (dist < ((s.typ_lo >> sh8) & 0xFF)) s.typ_lo = (s.typ_lo & ~(0xFFull << sh8)) | ((u64)dist << sh8);
+        }
+        slot_a = (int)mterm;
+    } else {
+        // rank_many_terms (docrank.c:218-328); term_to_word_idx's quirk reduces to term / 2
+        if ((int)mterm == nt - 1) s.comb = true;
+        const int widx = (int)mterm >> 1;
+        {
+            u64 &tw = widx < 8 ? s.typ_lo : s.typ_hi;
+            const int sh8 = (widx & 7) * 8;
+            if (dist < ((tw >> sh8) & 0xFF)) tw = (tw & ~(0xFFull << sh8)) | ((u64)dist << sh8);
+        }
+        slot_a = widx;
+        if (mterm & 1u) {
+            s.prox1 |= 1u << widx;
+            if ((int)mterm != nt - 1) {
+                const int w1 = widx + 1;
+                u64 &tw = w1 < 8 ? s.typ_lo : s.typ_hi;
+                tw &= ~(0xFFull << ((w1 & 7) * 8));
+                slot_b = w1;
+            }
+        }
+    }
+    if (first < s.bestpos) s.bestpos = first;          // runs are sorted: the first entry is the least
+    const bool keep_a = !(nw == 2 && slot_a == 2);     // the pair term only feeds best_position
+    for (uint32_t j = 0; j < cnt; j++) {
+        const uint32_t p = (j == 0) ? first : pp_doc[poff + j];
+        if (keep_a) { if (s.np < ps.cap) ps.set(s.np++, ((uint32_t)slot_a << 24) | p); else s.ovf = true; }
+        if (slot_b >= 0) { if (s.np < ps.cap) ps.set(s.np++, ((uint32_t)slot_b << 24) | p); else s.ovf = true; }
+    }
+}
 
-    exact_mask &= sq.exact_present;
+template <class PS>
+__device__ __forceinline__ void rank_finish(RankState &s, int nw, uint32_t exact_present, PS &ps, RankOut &ro) {
+    const uint32_t exact_mask = s.exact_mask & exact_present;
     ro.exact = (uint32_t)__popc(exact_mask);
     if (nw == 1) {
         ro.prox = 0;
         const bool ex = exact_mask & 1u;
-        uint32_t d = (uint32_t)(single_best >> 40);
-        if (single_best == ~0ull) d = 0xFF;
+        uint32_t d = (uint32_t)(s.single_best >> 40);
+        if (s.single_best == ~0ull) d = 0xFF;
         if (ex) {
             ro.typos = 0;
-            if (d == 0) { ro.field = (uint32_t)(single_best >> 16) & 0xFF; ro.pos = (uint32_t)single_best & 0xFFFF; }
+            if (d == 0) { ro.field = (uint32_t)(s.single_best >> 16) & 0xFF; ro.pos = (uint32_t)s.single_best & 0xFFFF; }
             else { ro.field = 0xFF; ro.pos = 0xFFFF; }
         } else if (d <= 0xFE) {
-            ro.typos = d; ro.field = (uint32_t)(single_best >> 16) & 0xFF; ro.pos = (uint32_t)single_best & 0xFFFF;
+            ro.typos = d; ro.field = (uint32_t)(s.single_best >> 16) & 0xFF; ro.pos = (uint32_t)s.single_best & 0xFFFF;
         } else { ro.typos = 0xFF; ro.field = 0xFF; ro.pos = 0xFFFF; }
-        return true;
+        return;
     }
     // typos: exact words and the all-words term zero them; the sum wraps like the reference's uint8_t
     uint32_t tsum = 0;
     for (int i = 0; i < nw; i++) {
-        uint32_t t = (uint32_t)(((i < 8 ? typ_lo : typ_hi) >> ((i & 7) * 8)) & 0xFF);
-        if (comb || ((exact_mask >> i) & 1u)) t = 0;
+        uint32_t t = (uint32_t)(((i < 8 ? s.typ_lo : s.typ_hi) >> ((i & 7) * 8)) & 0xFF);
+        if (s.comb || ((exact_mask >> i) & 1u)) t = 0;
         tsum += t;
     }
     ro.typos = tsum & 0xFF;
-    ro.field = (bestpos >> 16) & 0xFF;
-    ro.pos = bestpos & 0xFFFF;
-    if (comb) { ro.prox = (nw == 2) ? 1u : (uint32_t)(nw - 1); return true; }
-    sort_pairs(pairs, np);
-    // slot boundaries
+    ro.field = (s.bestpos >> 16) & 0xFF;
+    ro.pos = s.bestpos & 0xFFFF;
+    if (s.comb) { ro.prox = (nw == 2) ? 1u : (uint32_t)(nw - 1); return; }
+    const int np = s.np;
+    sort_pairs(ps, np);
     uint32_t prox = 0;
-    int idx = 0;
     int a0 = 0, a1 = 0;
-    while (idx < np && (int)(pairs[idx] >> 32) == 0) idx++;
-    a1 = idx;
+    while (a1 < np && (ps.get(a1) >> 24) == 0) a1++;
     for (int x = 0; x < nw - 1; x++) {
-        int b0 = a1, b1 = b0;
-        while (b1 < np && (int)(pairs[b1] >> 32) == x + 1) b1++;
-        if (nw > 2 && ((prox1 >> x) & 1u)) prox += 1;
-        else prox += (uint32_t)prox_walk(pairs, a0, a1, b0, b1);
+        const int b0 = a1; int b1 = b0;
+        while (b1 < np && (int)(ps.get(b1) >> 24) == x + 1) b1++;
+        if (nw > 2 && ((s.prox1 >> x) & 1u)) prox += 1;
+        else prox += (uint32_t)prox_walk(ps, a0, a1, b0, b1);
         a0 = b0; a1 = b1;
     }
     ro.prox = prox & 0xFFFF;
-    return true;
 }
 
 __device__ __forceinline__ u64 f64_order_key(double x) {
@@ -351,171 +376,264 @@ __device__ __forceinline__ void build_key(const SqDev &sq, const RankOut &ro, do
     hi = (u64)(key >> 64); lo = (u64)key;
 }
 
-// perform_doc_rank (docrank.c:414-443) for every hit: one document per lane.
-template <bool OVF>
-__global__ __launch_bounds__(MG_BLOCK) void k_rank(const SqDev *sqs, const uint32_t *blob,
-                                                   u64 *pool, uint32_t *pool_used, uint64_t pool_cap) {
-    const SqDev &sq = sqs[blockIdx.y];
-    const uint32_t M = OVF ? *sq.ovf_cnt : *sq.num_hits;
-    if (blockIdx.x * MG_BLOCK >= M) return;
-    __shared__ uint2 lds_tab[MG_LDS_HASH];
-    const uint2 *gtab = (const uint2 *)(blob + sq.hash_off);
-    const uint32_t hmask = sq.hash_mask;
-    const uint2 *htab = gtab;
-    if (sq.do_rank && hmask < MG_LDS_HASH) {
-        for (uint32_t i = threadIdx.x; i <= hmask; i += MG_BLOCK) lds_tab[i] = gtab[i];
-        __syncthreads();
-        htab = lds_tab;
-    }
-    const uint32_t t = blockIdx.x * MG_BLOCK + threadIdx.x;
-    u64 hi = 0, lo = 0;
-    bool have = false;
-    if (t < M) {
-        const uint32_t hidx = OVF ? sq.ovf_list[t] : t;
-        const uint32_t docid = sq.hits[hidx];
-        RankOut ro = {0, 0, 0, 0, 0};
-        bool ok = true;
-        if (sq.do_rank) {
-            if (!OVF) {
-                u64 pairs[MG_PCAP];
-                ok = rank_doc(sq, htab, hmask, docid, pairs, MG_PCAP, ro);
-                if (!ok) sq.ovf_list[atomicAdd(sq.ovf_cnt, 1u)] = hidx;
-            } else {
-                // bound of the pairs a document can produce: twice its token count
-                const uint32_t ntok = (sq.sh.dw_off[docid + 1] - sq.sh.dw_off[docid]) +
-                                      (sq.sh.pp_off[docid + 1] - sq.sh.pp_off[docid]);
-                const uint32_t need = 2 * ntok + 2;
-                const uint32_t at = atomicAdd(pool_used, need);
-                if ((uint64_t)at + need > pool_cap) { atomicMax(sq.err, (uint32_t)(-MGPU_E_SCRATCH)); ok = false; }
-                else ok = rank_doc(sq, htab, hmask, docid, pool + at, (int)need, ro);
-            }
-        }
-        if (ok) {
-            const double cmp = (sq.rank_by >= 0) ? sq.sh.num_col[sq.rank_by][docid] : 0.0;
-            build_key(sq, ro, cmp, hi, lo);
-            sq.key_hi[hidx] = hi; sq.key_lo[hidx] = lo;
-            have = true;
-        }
-    }
+__device__ __forceinline__ void or_key_bits(const SqDev &sq, u64 a, u64 b, u64 na, u64 nb) {
     // bits that differ between keys: OR of keys and OR of complements
-    u64 a = have ? hi : 0, b = have ? lo : 0, na = have ? ~hi : 0, nb = have ? ~lo : 0;
     a = wave_or64(a); b = wave_or64(b); na = wave_or64(na); nb = wave_or64(nb);
-    if ((threadIdx.x & 63) == 0) {
+    if ((threadIdx.x & 63) == 0 && (a | b | na | nb)) {
         atomicOr((u64 *)&sq.key_andor[0], na); atomicOr((u64 *)&sq.key_andor[1], nb);
         atomicOr((u64 *)&sq.key_andor[2], a);  atomicOr((u64 *)&sq.key_andor[3], b);
     }
+}
+
+// perform_doc_rank (docrank.c:414-443) for every hit, one tile of 256 hits per work item.
+// Phase 1 streams the docword runs of the tile: each group of 16 lanes takes one document at a
+// time and reads its run as one coalesced 128-byte load, keeping only the words the query
+// knows -- a handful per document -- as records in LDS.  Phase 2 ranks one document per lane from
+// its records.  Documents with more matches or positions than the LDS slices hold go to the
+// overflow list and are ranked by k_rank_overflow.
+extern __shared__ uint2 dyn_tab[];
+__global__ __launch_bounds__(MG_BLOCK) void k_rank_tile(const SqDev *sqs, const uint32_t *blob,
+                                                        const uint2 *tile_list, const uint32_t *tile_count) {
+    __shared__ uint32_t s_e0[MG_BLOCK], s_len[MG_BLOCK], s_cnt[MG_BLOCK];
+    __shared__ uint2 s_match[MG_BLOCK * MG_MCAP];
+    __shared__ uint32_t s_pairs[MG_BLOCK * MG_PCAP];
+    const uint32_t ntiles = *tile_count;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t grp = tid >> 4, gl = tid & 15;
+    for (uint32_t w = blockIdx.x; w < ntiles; w += gridDim.x) {
+        const uint2 item = tile_list[w];
+        const SqDev &sq = sqs[item.x];
+        const int do_rank = sq.do_rank;
+        if (do_rank < 0) continue;                   // no hits requested: nobody reads the keys
+        const uint32_t M = *sq.num_hits;
+        const uint32_t hmask = sq.hash_mask;
+        const uint2 *gtab = (const uint2 *)(blob + sq.hash_off);
+        const uint2 *htab = gtab;
+        const uint32_t t = item.y * MG_BLOCK + tid;
+        const bool valid = t < M;
+        const uint32_t docid = valid ? sq.hits[t] : 0;
+        uint32_t pbase = 0;
+        if (do_rank) {
+            if (hmask < MG_LDS_HASH) {
+                for (uint32_t i = tid; i <= hmask; i += MG_BLOCK) dyn_tab[i] = gtab[i];
+                htab = dyn_tab;
+            }
+            uint32_t e0 = 0, len = 0;
+            if (valid) { e0 = sq.sh.dw_off[docid]; len = sq.sh.dw_off[docid + 1] - e0; pbase = sq.sh.pp_off[docid]; }
+            s_e0[tid] = e0; s_len[tid] = len; s_cnt[tid] = 0;
+            __syncthreads();
+            const uint2 *dw = sq.sh.dw;
+            for (uint32_t d = grp; d < MG_BLOCK; d += MG_BLOCK / 16) {
+                const uint32_t len_d = s_len[d], e0_d = s_e0[d];
+                for (uint32_t j = gl; j < len_d; j += 16) {
+                    const uint2 wi = dw[e0_d + j];
+                    uint32_t val;
+                    if (probe_wid(htab, hmask, wi.x, val)) {
+                        const uint32_t r = atomicAdd(&s_cnt[d], 1u);
+                        if (r < MG_MCAP) s_match[d * MG_MCAP + r] = make_uint2(val, wi.y);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        u64 a = 0, b = 0, na = 0, nb = 0;
+        if (valid) {
+            RankOut ro = {0, 0, 0, 0, 0};
+            bool ok = true;
+            if (do_rank) {
+                const uint32_t cnt = s_cnt[tid];
+                if (cnt > MG_MCAP) ok = false;
+                else {
+                    RankState st; rank_init(st);
+                    LdsPairs ps = {&s_pairs[tid], MG_PCAP};
+                    const int nw = sq.num_words, nt = sq.num_terms;
+                    for (uint32_t r = 0; r < cnt; r++) {
+                        const uint2 m = s_match[tid * MG_MCAP + r];
+                        rank_consume(st, nw, nt, m.x, m.y, sq.sh.pp + pbase, ps);
+                    }
+                    if (st.ovf) ok = false; else rank_finish(st, nw, sq.exact_present, ps, ro);
+                }
+                if (!ok) sq.ovf_list[atomicAdd(sq.ovf_cnt, 1u)] = t;
+            }
+            if (ok) {
+                u64 hi, lo;
+                build_key(sq, ro, (sq.rank_by >= 0) ? sq.sh.num_col[sq.rank_by][docid] : 0.0, hi, lo);
+                sq.key_hi[t] = hi; sq.key_lo[t] = lo;
+                a = hi; b = lo; na = ~hi; nb = ~lo;
+            }
+        }
+        or_key_bits(sq, a, b, na, nb);
+        __syncthreads();                             // LDS is reused by the next work item
+    }
+}
+
+// The documents the tile kernel gave up on (long position lists): one document per lane, walking
+// its docwords serially with the pair store in the context's global pool.
+__global__ __launch_bounds__(MG_BLOCK) void k_rank_overflow(const SqDev *sqs, const uint32_t *blob,
+                                                            u64 *pool, uint32_t *pool_used, uint64_t pool_cap) {
+    const SqDev &sq = sqs[blockIdx.y];
+    if (sq.do_rank <= 0) return;
+    const uint32_t M = *sq.ovf_cnt;
+    if (blockIdx.x * MG_BLOCK >= M) return;
+    const uint2 *htab = (const uint2 *)(blob + sq.hash_off);
+    const uint32_t hmask = sq.hash_mask;
+    const int nw = sq.num_words, nt = sq.num_terms;
+    u64 a = 0, b = 0, na = 0, nb = 0;
+    for (uint32_t base = blockIdx.x * MG_BLOCK; base < M; base += gridDim.x * MG_BLOCK) {
+        const uint32_t t = base + threadIdx.x;
+        if (t >= M) continue;
+        const uint32_t hidx = sq.ovf_list[t];
+        const uint32_t docid = sq.hits[hidx];
+        const uint32_t e0 = sq.sh.dw_off[docid], e1 = sq.sh.dw_off[docid + 1];
+        const uint32_t pbase = sq.sh.pp_off[docid];
+        // bound of the pairs a document can produce: twice its token count
+        const uint32_t ntok = (e1 - e0) + (sq.sh.pp_off[docid + 1] - pbase);
+        const uint32_t need = ntok + 1;                  // u64 units = 2 packed pairs each
+        const uint32_t at = atomicAdd(pool_used, need);
+        if ((uint64_t)at + need > pool_cap) { atomicMax(sq.err, (uint32_t)(-MGPU_E_SCRATCH)); continue; }
+        RankState st; rank_init(st);
+        PoolPairs ps = {(uint32_t *)(pool + at), (int)(2 * need)};
+        for (uint32_t e = e0; e < e1; e++) {
+            const uint2 wi = sq.sh.dw[e];
+            uint32_t val;
+            if (probe_wid(htab, hmask, wi.x, val)) rank_consume(st, nw, nt, val, wi.y, sq.sh.pp + pbase, ps);
+        }
+        RankOut ro = {0, 0, 0, 0, 0};
+        rank_finish(st, nw, sq.exact_present, ps, ro);
+        u64 hi, lo;
+        build_key(sq, ro, (sq.rank_by >= 0) ? sq.sh.num_col[sq.rank_by][docid] : 0.0, hi, lo);
+        sq.key_hi[hidx] = hi; sq.key_lo[hidx] = lo;
+        a |= hi; b |= lo; na |= ~hi; nb |= ~lo;
+    }
+    or_key_bits(sq, a, b, na, nb);
+}
+
+// appends `v` to list[*n] for every lane whose `pred` is set, with one atomic per wave
+__device__ __forceinline__ void wave_append(bool pred, uint32_t v, uint32_t *list, uint32_t *n) {
+    const u64 m = __ballot(pred);
+    if (!m) return;
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+    uint32_t at = 0;
+    if (lane == leader) at = atomicAdd(n, (uint32_t)__popcll(m));
+    at = __shfl(at, leader, 64);
+    if (pred) list[at + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = v;
 }
 
 // ------------------------------------------------------------------ facets + aggregations
 // process_facet_result (docrank.c:371-389) and consume_*_agg (metric-aggs.c) over the hit list.
 // Facet ids were turned into dense ordinals by the mirror, so the hashtable of hashtable.c
 // becomes a histogram: privatised in LDS when the field has <= MG_LDS_HIST values.
-__global__ __launch_bounds__(MG_BLOCK) void k_docproc(const SqDev *sqs) {
-    const SqDev &sq = sqs[blockIdx.y];
-    if (blockIdx.x >= sq.nproc_blocks) return;
-    const uint32_t M = *sq.num_hits;
+__global__ __launch_bounds__(MG_BLOCK) void k_docproc(const SqDev *sqs, const uint2 *tile_list, const uint32_t *tile_count) {
     __shared__ uint32_t hist[MG_LDS_HIST];
     __shared__ AggPart red[MG_BLOCK / 64];
-    const uint32_t stride = sq.nproc_blocks * MG_BLOCK;
-    const uint32_t t0 = blockIdx.x * MG_BLOCK + threadIdx.x;
+    const uint32_t ntiles = *tile_count;
+    for (uint32_t w = blockIdx.x; w < ntiles; w += gridDim.x) {
+        const uint2 item = tile_list[w];
+        const SqDev &sq = sqs[item.x];
+        // The hit list is cut into nproc_blocks interleaved slices (fixed by the shard size so that
+        // the f64 reduction tree never depends on the batch); work item (sq, vb) is slice vb, and
+        // tiles beyond the slice count have nothing to add.
+        const uint32_t nvb = sq.nproc_blocks, vb = item.y;
+        if (vb >= nvb || (sq.hist_mask == 0 && sq.num_aggs == 0)) continue;
+        const uint32_t M = *sq.num_hits;
+        const uint32_t stride = nvb * MG_BLOCK;
 
-    for (int f = 0; f < sq.sh.num_facets; f++) {
-        if (!((sq.hist_mask >> f) & 1u)) continue;
-        const uint32_t nord = sq.sh.fa_nord[f];
-        const uint32_t *off = sq.sh.fa_off[f];
-        const uint32_t *ord = sq.sh.fa_ord[f];
-        uint32_t *gh = sq.hist[f];
-        const bool use_lds = nord <= MG_LDS_HIST;
-        if (use_lds) {
-            for (uint32_t i = threadIdx.x; i < nord; i += MG_BLOCK) hist[i] = 0;
-            __syncthreads();
-        }
-        for (uint32_t i = t0; i < M; i += stride) {
-            const uint32_t d = sq.hits[i];
-            const uint32_t a = off[d], b = off[d + 1];
-            for (uint32_t j = a; j < b; j++) {
-                const uint32_t o = ord[j];
-                if (use_lds) atomicAdd(&hist[o], 1u); else atomicAdd(&gh[o], 1u);
+        for (int f = 0; f < sq.sh.num_facets; f++) {
+            if (!((sq.hist_mask >> f) & 1u)) continue;
+            const uint32_t nord = sq.sh.fa_nord[f];
+            const uint32_t *off = sq.sh.fa_off[f];
+            const uint32_t *ord = sq.sh.fa_ord[f];
+            uint32_t *gh = sq.hist[f];
+            uint32_t *tl = sq.touched[f], *tn = sq.ntouched[f];
+            const bool use_lds = nord <= MG_LDS_HIST;
+            if (use_lds) {
+                for (uint32_t i = threadIdx.x; i < nord; i += MG_BLOCK) hist[i] = 0;
+                __syncthreads();
+            }
+            for (uint32_t i = vb * MG_BLOCK + threadIdx.x; i < M; i += stride) {
+                const uint32_t d = sq.hits[i];
+                const uint32_t a = off[d], b = off[d + 1];
+                for (uint32_t j = a; j < b; j++) {
+                    const uint32_t o = ord[j];
+                    if (use_lds) atomicAdd(&hist[o], 1u);
+                    else wave_append(atomicAdd(&gh[o], 1u) == 0, o, tl, tn);          // first touch: remember the bin
+                }
+            }
+            if (use_lds) {
+                __syncthreads();
+                for (uint32_t i0 = 0; i0 < nord; i0 += MG_BLOCK) {
+                    const uint32_t i = i0 + threadIdx.x;
+                    const uint32_t c = i < nord ? hist[i] : 0;
+                    wave_append(c && atomicAdd(&gh[i], c) == 0, i, tl, tn);
+                }
+                __syncthreads();
             }
         }
-        if (use_lds) {
-            __syncthreads();
-            for (uint32_t i = threadIdx.x; i < nord; i += MG_BLOCK) {
-                const uint32_t c = hist[i];
-                if (c) atomicAdd(&gh[i], c);
-            }
-            __syncthreads();
-        }
-    }
 
-    for (int a = 0; a < sq.num_aggs; a++) {
-        if (sq.agg_type[a] == MGPU_A_CARDINALITY) continue;
-        const double *col = sq.sh.num_col[sq.agg_field[a]];
-        double sum = 0.0, mn = 1.7976931348623157e308, mx = -1.7976931348623157e308;
-        unsigned long long cnt = 0;
-        for (uint32_t i = t0; i < M; i += stride) {
-            const double v = col[sq.hits[i]];
-            if (v != -1.7976931348623157e308) {          // get_num_value's "no value" marker, metric-aggs.c:106,149
-                sum += v; mn = v < mn ? v : mn; mx = v > mx ? v : mx; cnt++;
+        for (int a = 0; a < sq.num_aggs; a++) {
+            if (sq.agg_type[a] == MGPU_A_CARDINALITY) continue;
+            const double *col = sq.sh.num_col[sq.agg_field[a]];
+            double sum = 0.0, mn = 1.7976931348623157e308, mx = -1.7976931348623157e308;
+            unsigned long long cnt = 0;
+            for (uint32_t i = vb * MG_BLOCK + threadIdx.x; i < M; i += stride) {
+                const double v = col[sq.hits[i]];
+                if (v != -1.7976931348623157e308) {          // get_num_value's "no value" marker, metric-aggs.c:106,149
+                    sum += v; mn = v < mn ? v : mn; mx = v > mx ? v : mx; cnt++;
+                }
             }
-        }
-        // fixed-shape tree: lanes, then waves, so the f64 sum is reproducible run to run
+            // fixed-shape tree: lanes, then waves, so the f64 sum is reproducible run to run
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const double s2 = __shfl_down(sum, o, 64), n2 = __shfl_down(mn, o, 64), x2 = __shfl_down(mx, o, 64);
-            const unsigned long long c2 = __shfl_down(cnt, o, 64);
-            sum += s2; mn = n2 < mn ? n2 : mn; mx = x2 > mx ? x2 : mx; cnt += c2;
-        }
-        if ((threadIdx.x & 63) == 0) { AggPart p = {sum, mn, mx, cnt}; red[threadIdx.x >> 6] = p; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            AggPart p = red[0];
-            for (int w = 1; w < MG_BLOCK / 64; w++) {
-                p.sum += red[w].sum; p.mn = red[w].mn < p.mn ? red[w].mn : p.mn;
-                p.mx = red[w].mx > p.mx ? red[w].mx : p.mx; p.cnt += red[w].cnt;
+            for (int o = 32; o > 0; o >>= 1) {
+                const double s2 = __shfl_down(sum, o, 64), n2 = __shfl_down(mn, o, 64), x2 = __shfl_down(mx, o, 64);
+                const unsigned long long c2 = __shfl_down(cnt, o, 64);
+                sum += s2; mn = n2 < mn ? n2 : mn; mx = x2 > mx ? x2 : mx; cnt += c2;
             }
-            sq.agg_part[(size_t)blockIdx.x * sq.num_aggs + a] = p;
+            if ((threadIdx.x & 63) == 0) { AggPart p = {sum, mn, mx, cnt}; red[threadIdx.x >> 6] = p; }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                AggPart p = red[0];
+                for (int w2 = 1; w2 < MG_BLOCK / 64; w2++) {
+                    p.sum += red[w2].sum; p.mn = red[w2].mn < p.mn ? red[w2].mn : p.mn;
+                    p.mx = red[w2].mx > p.mx ? red[w2].mx : p.mx; p.cnt += red[w2].cnt;
+                }
+                sq.agg_part[(size_t)vb * sq.num_aggs + a] = p;
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
 }
 
-// combines the per-block partials in block order; one wave per squery
+// combines the per-slice partials in slice order; one wave per squery
 __global__ __launch_bounds__(64) void k_aggfinal(const SqDev *sqs) {
     const SqDev &sq = sqs[blockIdx.x];
     const int a = threadIdx.x;
     if (a >= sq.num_aggs || sq.agg_type[a] == MGPU_A_CARDINALITY) return;
+    const uint32_t M = *sq.num_hits;
+    const uint32_t tiles = (M + MG_BLOCK - 1) / MG_BLOCK;
+    const uint32_t nact = tiles < sq.nproc_blocks ? tiles : sq.nproc_blocks;
     AggPart p = {0.0, 1.7976931348623157e308, -1.7976931348623157e308, 0};
-    for (uint32_t b = 0; b < sq.nproc_blocks; b++) {
+    for (uint32_t b = 0; b < nact; b++) {
         const AggPart q = sq.agg_part[(size_t)b * sq.num_aggs + a];
         p.sum += q.sum; p.mn = q.mn < p.mn ? q.mn : p.mn; p.mx = q.mx > p.mx ? q.mx : p.mx; p.cnt += q.cnt;
     }
     sq.agg_out[a] = p;
 }
 
-// facet bins -> selection keys: smaller key = larger count, ties by facet id (squery.c:411-437)
-struct FkJob { const uint32_t *hist; const uint32_t *ord2id; uint32_t n; uint32_t pad; u64 *key_hi, *key_lo;
-               uint32_t *nnz; u64 *andor; };
-// Only bins that were hit become keys (wave-ballot compaction), and the bits that differ between
-// keys are recorded so the radix select skips the constant ones.
+// touched facet bins -> selection keys: smaller key = larger count, ties by facet id (squery.c:411-437).
+// Key i belongs to the i-th touched bin; the bits that differ between keys are recorded so the
+// radix select skips the constant ones.
+struct FkJob { const uint32_t *hist; const uint32_t *ord2id; const uint32_t *touched; const uint32_t *ntouched;
+               u64 *key_hi, *key_lo; u64 *andor; };
 __global__ __launch_bounds__(MG_BLOCK) void k_fkeys(const FkJob *jobs) {
     const FkJob j = jobs[blockIdx.y];
+    const uint32_t n = *j.ntouched;
     const int lane = threadIdx.x & 63;
     u64 a = 0, b = 0, na = 0, nb = 0;
-    for (uint32_t base = blockIdx.x * MG_BLOCK; base < j.n; base += gridDim.x * MG_BLOCK) {
-        const uint32_t i = base + threadIdx.x;
-        const uint32_t c = (i < j.n) ? j.hist[i] : 0;
-        const bool nz = c != 0;
-        const u64 m = __ballot(nz);
-        uint32_t wbase = 0;
-        if (lane == 0 && m) wbase = atomicAdd(j.nnz, (uint32_t)__popcll(m));
-        wbase = __shfl(wbase, 0, 64);
-        if (nz) {
-            const uint32_t at = wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1));
-            const u64 hi = (u64)(0xFFFFFFFFu - c), lo = j.ord2id[i];
-            j.key_hi[at] = hi; j.key_lo[at] = lo;
-            a |= hi; b |= lo; na |= ~hi; nb |= ~lo;
-        }
+    for (uint32_t i = blockIdx.x * MG_BLOCK + threadIdx.x; i < n; i += gridDim.x * MG_BLOCK) {
+        const uint32_t bin = j.touched[i];
+        const u64 hi = (u64)(0xFFFFFFFFu - j.hist[bin]), lo = j.ord2id[bin];
+        j.key_hi[i] = hi; j.key_lo[i] = lo;
+        a |= hi; b |= lo; na |= ~hi; nb |= ~lo;
     }
     a = wave_or64(a); b = wave_or64(b); na = wave_or64(na); nb = wave_or64(nb);
     if (lane == 0 && (a | b | na | nb)) {
@@ -524,20 +642,14 @@ __global__ __launch_bounds__(MG_BLOCK) void k_fkeys(const FkJob *jobs) {
     }
 }
 
-// distinct facet ids among the hits (cardinality agg, metric-aggs.c:23-45,47-55): nonzero bins
-struct CardJob { const uint32_t *hist; const uint32_t *ord2id; uint32_t n; uint32_t pad; uint32_t *out_ids; uint32_t *out_n; };
+// distinct facet ids among the hits (cardinality agg, metric-aggs.c:23-45,47-55): the touched bins
+struct CardJob { const uint32_t *ord2id; const uint32_t *touched; const uint32_t *ntouched; uint32_t *out_ids; uint32_t *out_n; };
 __global__ __launch_bounds__(MG_BLOCK) void k_card(const CardJob *jobs) {
     const CardJob j = jobs[blockIdx.y];
-    for (uint32_t base = blockIdx.x * MG_BLOCK; base < j.n; base += gridDim.x * MG_BLOCK) {
-        const uint32_t i = base + threadIdx.x;
-        const bool nz = (i < j.n) && j.hist[i] != 0;
-        const u64 m = __ballot(nz);
-        const int lane = threadIdx.x & 63;
-        uint32_t wbase = 0;
-        if (lane == 0 && m) wbase = atomicAdd(j.out_n, (uint32_t)__popcll(m));
-        wbase = __shfl(wbase, 0, 64);
-        if (nz) j.out_ids[wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = j.ord2id[i];
-    }
+    const uint32_t n = *j.ntouched;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *j.out_n = n;
+    for (uint32_t i = blockIdx.x * MG_BLOCK + threadIdx.x; i < n; i += gridDim.x * MG_BLOCK)
+        j.out_ids[i] = j.ord2id[j.touched[i]];
 }
 
 // ------------------------------------------------------------------ top-k selection
@@ -553,17 +665,26 @@ __device__ __forceinline__ uint32_t key_bit(u64 hi, u64 lo, uint32_t idx, uint32
 __device__ __forceinline__ bool mask_bit(u64 mhi, u64 mlo, uint32_t midx, uint32_t b) {
     return key_bit(mhi, mlo, midx, b) != 0;
 }
-// positions of the next MG_SEL_DIGIT varying bits at or after `from`; returns how many, *next = scan position after
-__device__ __forceinline__ int digit_bits(u64 mhi, u64 mlo, uint32_t midx, uint32_t from, uint8_t *pos, uint32_t *next) {
+// positions of the next MG_SEL_DIGIT varying bits at or after `from`, written as (word << 8 | shift)
+// with word 0 = hi, 1 = lo, 2 = idx; returns how many, *next = scan position after.
+// Called by one thread; the table lives in LDS so that no kernel here needs private arrays.
+__device__ __forceinline__ int digit_bits(u64 mhi, u64 mlo, uint32_t midx, uint32_t from, uint32_t *pos, uint32_t *next) {
     int n = 0;
     uint32_t b = from;
-    for (; b < 160 && n < MG_SEL_DIGIT; b++) if (mask_bit(mhi, mlo, midx, b)) pos[n++] = (uint8_t)b;
+    for (; b < 160 && n < MG_SEL_DIGIT; b++) {
+        if (!mask_bit(mhi, mlo, midx, b)) continue;
+        pos[n++] = b < 64 ? (63 - b) : b < 128 ? ((1u << 8) | (127 - b)) : ((2u << 8) | (159 - b));
+    }
     *next = b;
     return n;
 }
-__device__ __forceinline__ uint32_t digit_of(u64 hi, u64 lo, uint32_t idx, const uint8_t *pos, int n) {
+__device__ __forceinline__ uint32_t digit_of(u64 hi, u64 lo, uint32_t idx, const uint32_t *pos, int n) {
     uint32_t d = 0;
-    for (int j = 0; j < n; j++) d = (d << 1) | key_bit(hi, lo, idx, pos[j]);
+    for (int j = 0; j < n; j++) {
+        const uint32_t e = pos[j], w = e >> 8, sh = e & 0xFF;
+        const u64 v = w == 0 ? hi : w == 1 ? lo : (u64)idx;
+        d = (d << 1) | (uint32_t)((v >> sh) & 1u);
+    }
     return d;
 }
 __device__ __forceinline__ void job_masks(const SelJob &job, uint32_t M, u64 &mhi, u64 &mlo, uint32_t &midx) {
@@ -599,6 +720,7 @@ __global__ __launch_bounds__(MG_BLOCK) void k_select_pass(const SelJob *jobs) {
     __shared__ uint32_t s_ctl[SEL_WORDS];
     __shared__ uint32_t s_scan[8];
     __shared__ uint32_t s_last, s_nout, s_nwin, s_dstar, s_cum;
+    __shared__ uint32_t s_pprev[MG_SEL_DIGIT], s_pcur[MG_SEL_DIGIT], s_nprev, s_ncur, s_nextbit;
     u64 mhi, mlo; uint32_t midx;
     job_masks(job, M, mhi, mlo, midx);
     const int lane = threadIdx.x & 63;
@@ -621,19 +743,22 @@ __global__ __launch_bounds__(MG_BLOCK) void k_select_pass(const SelJob *jobs) {
         const bool solo = nb == 1;
 
         for (uint32_t i = threadIdx.x; i < MG_SEL_BINS; i += MG_BLOCK) hist[i] = 0;
-        if (threadIdx.x == 0) { s_nout = 0; s_nwin = s_ctl[SEL_NWIN]; s_dstar = 0xFFFFFFFFu; s_cum = 0; }
-        uint8_t pprev[MG_SEL_DIGIT], pcur[MG_SEL_DIGIT];
-        int nprev = 0; uint32_t dummy;
         const uint32_t bitpos = (pass == 0) ? 0 : s_ctl[SEL_BITPOS];
-        if (pass > 0) nprev = digit_bits(mhi, mlo, midx, s_ctl[SEL_BPREV], pprev, &dummy);
-        uint32_t next_bitpos;
-        const int ncur = digit_bits(mhi, mlo, midx, bitpos, pcur, &next_bitpos);
+        if (threadIdx.x == 0) {
+            s_nout = 0; s_nwin = s_ctl[SEL_NWIN]; s_dstar = 0xFFFFFFFFu; s_cum = 0;
+            uint32_t dummy, nb2;
+            s_nprev = (pass > 0) ? (uint32_t)digit_bits(mhi, mlo, midx, s_ctl[SEL_BPREV], s_pprev, &dummy) : 0u;
+            s_ncur = (uint32_t)digit_bits(mhi, mlo, midx, bitpos, s_pcur, &nb2);
+            s_nextbit = nb2;
+        }
         const uint32_t dstar = s_ctl[SEL_DSTAR];
         const uint32_t buf = s_ctl[SEL_BUF];
         const uint32_t *rin = (pass <= 1) ? nullptr : job.cand[buf];
         uint32_t *rout = job.cand[buf ^ (pass <= 1 ? 0u : 1u)];
         uint32_t *win = job.out_idx;        // winners accumulate in the output buffer, sorted at the end
         __syncthreads();
+        const int nprev = (int)s_nprev, ncur = (int)s_ncur;
+        const uint32_t next_bitpos = s_nextbit;
 
         const uint32_t nch = (nin + SEL_CHUNK - 1) / SEL_CHUNK;
         for (uint32_t ch = vbid; ch < nch; ch += nb) {
@@ -647,7 +772,7 @@ __global__ __launch_bounds__(MG_BLOCK) void k_select_pass(const SelJob *jobs) {
                     hi = job.key_hi[idx]; lo = job.key_lo[idx];
                     keep = true;
                     if (pass > 0) {
-                        const uint32_t dp = digit_of(hi, lo, idx, pprev, nprev);
+                        const uint32_t dp = digit_of(hi, lo, idx, s_pprev, nprev);
                         if (dp < dstar) { winner = true; keep = false; }
                         else if (dp > dstar) keep = false;
                     }
@@ -670,7 +795,7 @@ __global__ __launch_bounds__(MG_BLOCK) void k_select_pass(const SelJob *jobs) {
                     if (keep) rout[bk + (uint32_t)__popcll(mk & below)] = idx;
                     if (winner) win[bw + (uint32_t)__popcll(mw & below)] = idx;
                 }
-                if (keep) atomicAdd(&hist[digit_of(hi, lo, idx, pcur, ncur)], 1u);
+                if (keep) atomicAdd(&hist[digit_of(hi, lo, idx, s_pcur, ncur)], 1u);
             }
         }
         __syncthreads();
@@ -771,12 +896,16 @@ __global__ __launch_bounds__(MG_BLOCK) void k_select_final(const SelJob *jobs, c
     const uint32_t nwin = ctl[SEL_NWIN];
     u64 mhi, mlo; uint32_t midx;
     job_masks(job, M, mhi, mlo, midx);
-    uint8_t pprev[MG_SEL_DIGIT]; int nprev = 0; uint32_t dummy;
-    if (pass > 0) nprev = digit_bits(mhi, mlo, midx, ctl[SEL_BPREV], pprev, &dummy);
+    __shared__ uint32_t s_pprev[MG_SEL_DIGIT], s_nprev;
     const uint32_t dstar = ctl[SEL_DSTAR];
     const uint32_t *rin = (pass <= 1) ? nullptr : job.cand[ctl[SEL_BUF]];
-    if (threadIdx.x == 0) s_n = 0;
+    if (threadIdx.x == 0) {
+        s_n = 0;
+        uint32_t dummy;
+        s_nprev = (pass > 0) ? (uint32_t)digit_bits(mhi, mlo, midx, ctl[SEL_BPREV], s_pprev, &dummy) : 0u;
+    }
     __syncthreads();
+    const int nprev = (int)s_nprev;
     // winners found by the passes
     for (uint32_t i = threadIdx.x; i < nwin; i += MG_BLOCK) {
         const uint32_t idx = job.out_idx[i];
@@ -788,7 +917,7 @@ __global__ __launch_bounds__(MG_BLOCK) void k_select_final(const SelJob *jobs, c
         const uint32_t idx = rin ? rin[i] : i;
         const u64 hi = job.key_hi[idx], lo = job.key_lo[idx];
         bool take = true;
-        if (pass > 0) take = digit_of(hi, lo, idx, pprev, nprev) <= dstar;
+        if (pass > 0) take = digit_of(hi, lo, idx, s_pprev, nprev) <= dstar;
         if (take) {
             const uint32_t p = atomicAdd(&s_n, 1u);
             if (p < CAP) { s_hi[p] = hi; s_lo[p] = lo; s_ix[p] = idx; }
@@ -851,29 +980,44 @@ void mgk_scatter(hipStream_t st, const ScatterItem *items, uint32_t nitems) {
     uint32_t grid = nitems < 8192 ? nitems : 8192;
     hipLaunchKernelGGL(k_scatter, dim3(grid), dim3(MG_BLOCK), 0, st, items, nitems);
 }
-void mgk_formula(hipStream_t st, const SqDev *sqs, const uint32_t *blob, uint32_t max_nblk, uint32_t nsq) {
+// number of workgroups of the persistent kernels that stride over the tile work list
+static uint32_t worklist_grid(uint32_t tile_cap) {
+    uint32_t g = 256 * 8;                                  // 256 CUs, a few workgroups each
+    if (g > tile_cap) g = tile_cap;
+    return g ? g : 1;
+}
+void mgk_formula(hipStream_t st, const SqDev *sqs, const uint32_t *blob, uint32_t max_nblk, uint32_t nsq,
+                 uint2 *tile_list, uint32_t *tile_count) {
     hipLaunchKernelGGL(k_formula, dim3(max_nblk, nsq), dim3(MG_BLOCK), 0, st, sqs, blob);
-    hipLaunchKernelGGL(k_scan, dim3(nsq), dim3(MG_BLOCK), 0, st, sqs);
+    hipLaunchKernelGGL(k_scan, dim3(nsq), dim3(MG_BLOCK), 0, st, sqs, tile_list, tile_count);
     hipLaunchKernelGGL(k_compact, dim3(max_nblk, nsq), dim3(MG_BLOCK), 0, st, sqs);
 }
 void mgk_rank(hipStream_t st, const SqDev *sqs, const uint32_t *blob, uint32_t max_n, uint32_t nsq,
+              uint32_t max_tab_slots, const uint2 *tile_list, const uint32_t *tile_count, uint32_t tile_cap,
               unsigned long long *pool, uint32_t *pool_used, uint64_t pool_cap) {
-    uint32_t gx = (max_n + MG_BLOCK - 1) / MG_BLOCK;
-    hipLaunchKernelGGL(k_rank<false>, dim3(gx, nsq), dim3(MG_BLOCK), 0, st, sqs, blob, pool, pool_used, pool_cap);
-    hipLaunchKernelGGL(k_rank<true>, dim3(gx, nsq), dim3(MG_BLOCK), 0, st, sqs, blob, pool, pool_used, pool_cap);
+    if (max_tab_slots > MG_LDS_HASH) max_tab_slots = MG_LDS_HASH;
+    hipLaunchKernelGGL(k_rank_tile, dim3(worklist_grid(tile_cap)), dim3(MG_BLOCK), (size_t)max_tab_slots * sizeof(uint2), st,
+                       sqs, blob, tile_list, tile_count);
+    uint32_t gy = (max_n + MG_BLOCK - 1) / MG_BLOCK;
+    uint32_t cap = 4096 / nsq; if (cap < 4) cap = 4;
+    if (gy > cap) gy = cap;
+    hipLaunchKernelGGL(k_rank_overflow, dim3(gy, nsq), dim3(MG_BLOCK), 0, st, sqs, blob, pool, pool_used, pool_cap);
 }
-void mgk_docproc(hipStream_t st, const SqDev *sqs, uint32_t max_pblocks, uint32_t nsq) {
-    hipLaunchKernelGGL(k_docproc, dim3(max_pblocks, nsq), dim3(MG_BLOCK), 0, st, sqs);
+void mgk_docproc(hipStream_t st, const SqDev *sqs, uint32_t nsq, const uint2 *tile_list, const uint32_t *tile_count,
+                 uint32_t tile_cap) {
+    hipLaunchKernelGGL(k_docproc, dim3(worklist_grid(tile_cap)), dim3(MG_BLOCK), 0, st, sqs, tile_list, tile_count);
     hipLaunchKernelGGL(k_aggfinal, dim3(nsq), dim3(64), 0, st, sqs);
 }
 void mgk_fkeys(hipStream_t st, const void *jobs, uint32_t njobs, uint32_t max_n) {
     if (!njobs) return;
-    uint32_t gx = (max_n + MG_BLOCK - 1) / MG_BLOCK; if (gx > 256) gx = 256; if (!gx) gx = 1;
+    uint32_t gx = (max_n + MG_BLOCK - 1) / MG_BLOCK, cap = 8192 / njobs; if (cap < 4) cap = 4;
+    if (gx > cap) gx = cap; if (!gx) gx = 1;
     hipLaunchKernelGGL(k_fkeys, dim3(gx, njobs), dim3(MG_BLOCK), 0, st, (const FkJob *)jobs);
 }
 void mgk_card(hipStream_t st, const void *jobs, uint32_t njobs, uint32_t max_n) {
     if (!njobs) return;
-    uint32_t gx = (max_n + MG_BLOCK - 1) / MG_BLOCK; if (gx > 256) gx = 256; if (!gx) gx = 1;
+    uint32_t gx = (max_n + MG_BLOCK - 1) / MG_BLOCK, cap = 8192 / njobs; if (cap < 4) cap = 4;
+    if (gx > cap) gx = cap; if (!gx) gx = 1;
     hipLaunchKernelGGL(k_card, dim3(gx, njobs), dim3(MG_BLOCK), 0, st, (const CardJob *)jobs);
 }
 void mgk_select(hipStream_t st, const SelJob *jobs, const void *outs, uint32_t njobs, uint32_t max_m, int passes) {

@@ -6,7 +6,8 @@
 #define MG_BLOCK        256          // threads per workgroup (4 waves of 64)
 #define MG_WORDS_PER_BLOCK 256       // u64 bitmap words handled by one formula/compact block
 #define MG_MAX_STACK    8            // filter program stack depth
-#define MG_PCAP         24           // in-register (slot,position) pairs per document before overflow
+#define MG_MCAP         8            // matched docwords kept per document in LDS before the overflow path
+#define MG_PCAP         12           // (slot,position) pairs per document in LDS before the overflow path
 #define MG_SEL_BINS     2048         // radix-select digit = 11 bits
 #define MG_SEL_DIGIT    11
 #define MG_SEL_PASSES   3            // select passes launched per round (lists <= 32768 finish inside one launch)
@@ -97,6 +98,8 @@ struct SqDev {
     // ---- doc processing (facets + aggs) ----
     uint32_t hist_mask;              // bit f: histogram field f
     uint32_t *hist[MGPU_MAX_FIELDS]; // [fa_nord[f]] zeroed per query
+    uint32_t *touched[MGPU_MAX_FIELDS];  // [fa_nord[f]] bins hit at least once, in first-touch order
+    uint32_t *ntouched[MGPU_MAX_FIELDS]; // device word, zeroed per query
     int32_t  num_aggs;
     int32_t  agg_type[MGPU_MAX_AGGS];
     int32_t  agg_field[MGPU_MAX_AGGS];
@@ -105,7 +108,6 @@ struct SqDev {
     uint32_t nproc_blocks;
     // facet selection keys
     uint64_t *fkey_hi[MGPU_MAX_FIELDS], *fkey_lo[MGPU_MAX_FIELDS];
-    uint32_t *fnnz[MGPU_MAX_FIELDS];   // number of bins (device word, = fa_nord)
     // ---- status ----
     uint32_t *err;                   // device word, nonzero = MGPU_E_* (negated)
 };

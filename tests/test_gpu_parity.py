@@ -74,3 +74,25 @@ def test_single_query_equals_batched(dg):
     a = eng.search(pq)
     b = eng.search([pq, pq, pq])
     assert all(x["ranks"] == a["ranks"] and x["facets"] == a["facets"] for x in b)
+
+
+def test_long_position_lists_take_the_overflow_path():
+    """documents whose matched words or positions exceed the LDS slices of the rank kernel
+    (MG_MCAP matched words, MG_PCAP positions) are ranked by the overflow kernel"""
+    docs = []
+    for i in range(300):
+        rep = 1 + (i % 40)
+        body = " ".join((["alpha"] * rep) + ["x%d" % j for j in range(i % 7)] + (["beta"] * (1 + i % 23)) + ["gamma"])
+        docs.append({"id": i, "str": body, "other": "alpha beta gamma delta " * (i % 5), "num": i % 13})
+    settings = {"indexedFields": ["str", "other", "num"], "facetFields": [], "hitsPerPage": 50}
+    ix = Index(settings, num_shards=2).add_documents(docs)
+    eng = GpuEngine(ix)
+    try:
+        qs = [{"q": "alpha beta"}, {"q": "alpha beta gamma"}, {"q": "beta alpha gamma delta"}, {"q": "alpha"},
+              {"q": "alphx betb gamma", "rankBy": {"num": "desc"}}]
+        pqs = [ix.query(dict(q, fullScan=True)) for q in qs]
+        got = eng.search(pqs, capture=3)
+        for pq, g in zip(pqs, got):
+            compare_results(g, orc_py.search(ix, pq, flags=3), ctx=pq.jq)
+    finally:
+        eng.close(); ix.close()
