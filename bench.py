@@ -122,12 +122,10 @@ def main():
     def batch_queries(step):
         return [pool[(step * B + i) % nq_pool] for i in range(B)]
 
-    gather_buf = None
+    gather = None
     if world > 1:
-        send = torch.empty(B * local * slot_b, dtype=torch.uint8, device="cuda")
-        recv = torch.empty(world * B * local * slot_b, dtype=torch.uint8, device="cuda")
-        host_send = torch.empty(B * local * slot_b, dtype=torch.uint8).pin_memory()
-        host_recv = torch.empty(world * B * local * slot_b, dtype=torch.uint8).pin_memory()
+        from marlin_amd.dist import ShardGather
+        gather = ShardGather(lib, dist, world, rank, B, local, K_TOP, NF, FMAX, NAGG, device="cuda:%d" % local_rank)
 
     # Term lookup (the dtrie walk of lookup_terms) is outside the north-star path ("per-shard
     # query execution after term lookup"): resolve it once per distinct batch, before timing.
@@ -145,17 +143,10 @@ def main():
         if world == 1:
             hits = lib.m_form_result_batch(qarr, outs, B, local, None, 0)
         else:
-            lib.m_slot_pack_batch(outs, B * local, K_TOP, NF, FMAX, NAGG, host_send.data_ptr())
-            send.copy_(host_send, non_blocking=True)
-            dist.all_gather_into_tensor(recv, send)
-            if rank == 0:
-                host_recv.copy_(recv, non_blocking=True)
-                torch.cuda.synchronize()
-                sq = (ffi.SqResult * (B * TOTAL_SHARDS))()
-                lib.m_slot_unpack_gathered(host_recv.data_ptr(), world, B, local, K_TOP, NF, FMAX, NAGG, sq)
+            sq = gather.gather(outs)                 # one RCCL all_gather of fixed-size result slots
+            if sq is not None:
                 hits = lib.m_form_result_batch(qarr, sq, B, TOTAL_SHARDS, None, 0)
-                for i in range(B * TOTAL_SHARDS):
-                    lib.m_sqresult_free(C.byref(sq[i]))
+                gather.free(sq)
         eng.free_raw(outs)
         return hits
 

@@ -1,0 +1,55 @@
+"""Shards <-> GPUs: the cross-rank step of a sharded query.
+
+The reference runs one execute_squery per shard on a thread pool inside one process and merges
+the per-shard results in form_result (query.c:319-383).  Here a rank (= one process = one GPU)
+owns a contiguous block of shards; after the GPU batch every rank packs its per-(query, shard)
+results into fixed-size slots (m_slot_pack_batch), one all_gather moves them (RCCL over xGMI when
+the tensors live on the GPUs, gloo on CPU in the tests) and rank 0 unpacks and merges with the
+same m_form_result the single-GPU path uses.  There is no other collective on the data path.
+"""
+import ctypes as C
+
+from . import ffi
+
+
+class ShardGather:
+    def __init__(self, lib, dist, world, rank, nq, local_shards, k_top, num_facets, fmax, num_aggs, device=None):
+        import torch
+        self.lib, self.dist, self.world, self.rank = lib, dist, world, rank
+        self.nq, self.local = nq, local_shards
+        self.shape = (k_top, num_facets, fmax, num_aggs)
+        self.slot_b = lib.m_slot_bytes(*self.shape)
+        n = nq * local_shards * self.slot_b
+        self.on_gpu = device is not None and str(device).startswith("cuda")
+        self.host_send = torch.empty(n, dtype=torch.uint8)
+        self.host_recv = torch.empty(world * n, dtype=torch.uint8)
+        if self.on_gpu:
+            self.host_send = self.host_send.pin_memory(); self.host_recv = self.host_recv.pin_memory()
+            self.send = torch.empty(n, dtype=torch.uint8, device=device)
+            self.recv = torch.empty(world * n, dtype=torch.uint8, device=device)
+        self.torch = torch
+
+    def gather(self, outs):
+        """outs: ctypes SqResult array [query][local shard] of this rank.  Returns, on rank 0, a
+        SqResult array [query][global shard] the caller frees with free(); None elsewhere."""
+        lib = self.lib
+        lib.m_slot_pack_batch(outs, self.nq * self.local, *self.shape, self.host_send.data_ptr())
+        if self.on_gpu:
+            self.send.copy_(self.host_send, non_blocking=True)
+            self.dist.all_gather_into_tensor(self.recv, self.send)
+            if self.rank != 0:
+                return None
+            self.host_recv.copy_(self.recv, non_blocking=True)
+            self.torch.cuda.synchronize()
+        else:
+            self.dist.all_gather_into_tensor(self.host_recv, self.host_send)
+            if self.rank != 0:
+                return None
+        total = self.world * self.local
+        sq = (ffi.SqResult * (self.nq * total))()
+        lib.m_slot_unpack_gathered(self.host_recv.data_ptr(), self.world, self.nq, self.local, *self.shape, sq)
+        return sq
+
+    def free(self, sq):
+        for i in range(len(sq)):
+            self.lib.m_sqresult_free(C.byref(sq[i]))
