@@ -193,11 +193,14 @@ def main():
     stage_tab = {}
     eng.set_profiling(True)
     acc = {}
+    host_acc = {}
     nprof = 5
     for s in range(nprof):
         o = eng.execute_prepared(prepared[s % nbatches])
         eng.free_raw(o)
         tm = eng.timing()
+        for hk, hv in tm["host_ms"].items():
+            host_acc[hk] = host_acc.get(hk, 0.0) + hv / nprof
         for name, v in tm["stages"].items():
             a = acc.setdefault(name, [0.0, 0])
             a[0] += v["ms"]; a[1] += v["bytes"]
@@ -248,6 +251,7 @@ def main():
                            "with_term_lookup_p50": round(lat_full[len(lat_full) // 2], 3),
                            "with_term_lookup_p99": round(lat_full[int(len(lat_full) * 0.99)], 3)} if lat else None,
             "stages": stage_tab,
+            "host_ms_per_step": {k: round(v, 3) for k, v in host_acc.items()},
             "setup_s": {"build_shards": round(t_build, 1), "mirror": round(t_mirror, 1), "term_lookup": round(t_prepare, 2)},
             "mirror_GB": round(mirror_bytes / 1e9, 3),
         }

@@ -175,6 +175,8 @@ void mgpu_sqout_free(mgpu_sqout_t *o);
 #define MGPU_NUM_STAGES 8
 int  mgpu_last_timing(const mgpu_ctx_t *c, float *total_ms, float *stage_ms /* [MGPU_NUM_STAGES] */);
 const char *mgpu_stage_name(int stage);
+/* host wall-clock ms of the last mgpu_execute: [0] plan lowering + staging, [1] launches + wait, [2] result decode */
+int  mgpu_last_host_timing(const mgpu_ctx_t *c, float *host_ms /* [3] */);
 /* algorithmic bytes moved by the last mgpu_execute per stage (DESIGN.md byte model) */
 int  mgpu_last_bytes(const mgpu_ctx_t *c, uint64_t *stage_bytes /* [MGPU_NUM_STAGES] */);
 /* enable/disable per-stage event timing (adds event records between kernels) */

@@ -3,6 +3,7 @@
 // Mirror construction (reference formats -> HBM layouts), per-batch plan lowering, arena
 // layout, launches on one HIP stream, result decode.  No torch, no CPU compute fallback:
 // every documented failure returns an MGPU_E_* code.
+#include <time.h>
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
@@ -25,7 +26,7 @@ void mgk_docproc(hipStream_t st, const SqDev *sqs, uint32_t nsq, const uint2 *ti
                  uint32_t tile_cap);
 void mgk_fkeys(hipStream_t st, const void *jobs, uint32_t njobs, uint32_t max_n);
 void mgk_card(hipStream_t st, const void *jobs, uint32_t njobs, uint32_t max_n);
-void mgk_select(hipStream_t st, const SelJob *jobs, const void *outs, uint32_t njobs, uint32_t max_m, int passes);
+void mgk_select(hipStream_t st, const SelJob *jobs, const void *outs, uint32_t njobs, uint32_t max_m, int passes, int finals);
 void mgk_row_op(hipStream_t st, const unsigned long long *a, const unsigned long long *b, unsigned long long *out,
                 uint32_t W, int op, unsigned long long *card);
 }
@@ -227,6 +228,7 @@ struct mgpu_ctx {
     int profiling;
     float stage_ms[MGPU_NUM_STAGES];
     float total_ms;
+    float host_ms[3];               // last mgpu_execute: lowering, launch + wait, decode (wall clock)
     uint64_t stage_bytes[MGPU_NUM_STAGES];
 };
 
@@ -264,6 +266,13 @@ extern "C" void mgpu_ctx_set_profiling(mgpu_ctx_t *c, int on) { if (c) c->profil
 static const char *k_stage_names[MGPU_NUM_STAGES] = {
     "upload+clear", "scatter", "formula+compact", "rank", "facets+aggs", "facet-keys", "select", "download" };
 extern "C" const char *mgpu_stage_name(int s) { return (s >= 0 && s < MGPU_NUM_STAGES) ? k_stage_names[s] : ""; }
+
+extern "C" int mgpu_last_host_timing(const mgpu_ctx_t *c, float *host_ms) {
+    if (!c || !host_ms) return fail(MGPU_E_ARG, "bad argument");
+    memcpy(host_ms, c->host_ms, sizeof(c->host_ms));
+    return MGPU_OK;
+}
+static double wall_ms() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
 
 extern "C" int mgpu_last_timing(const mgpu_ctx_t *c, float *total_ms, float *stage_ms) {
     if (!c) return MGPU_E_ARG;
@@ -392,6 +401,7 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
     if (n > 65535) return fail(MGPU_E_LIMIT, "batch larger than 65535");
     HIPCHK(hipSetDevice(c->device));
     for (int i = 0; i < n; i++) memset(&outs[i], 0, sizeof(outs[i]));
+    const double t_begin = wall_ms();
 
     // ---------------- lower plans into host staging ----------------
     std::vector<SqDev> sqd(n);
@@ -752,6 +762,7 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
     if (!cardjobs.empty()) memcpy(c->pin + up_card, cardjobs.data(), cardjobs.size() * sizeof(CardJob));
 
     // ---------------- launches ----------------
+    const double t_lowered = wall_ms();
     hipStream_t st = c->stream;
     const SqDev *d_sq = (const SqDev *)(UP + up_sq);
     const uint32_t *d_blob = (const uint32_t *)(UP + up_blob);
@@ -775,14 +786,15 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
     mgk_fkeys(st, UP + up_fk, (uint32_t)fkjobs.size(), max_fk);
     mgk_card(st, UP + up_card, (uint32_t)cardjobs.size(), max_fk);
     mark();
-    mgk_select(st, (const SelJob *)(UP + up_sel), UP + up_selout, (uint32_t)seljobs.size(), max_selm, MG_SEL_PASSES);
+    mgk_select(st, (const SelJob *)(UP + up_sel), UP + up_selout, (uint32_t)seljobs.size(), max_selm, 1, 0);
     mark();
     HIPCHK(hipMemcpyAsync(c->pin_out, R, res_bytes, hipMemcpyDeviceToHost, st));
     if (prof) { (void)hipEventRecord(c->ev[evi++], st); } else { (void)hipEventRecord(c->ev[1], st); }
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
 
-    // a selection that needed more than MG_SEL_PASSES passes: run further rounds
+    // jobs the first pass launch did not finish (lists of more than 32768 keys, or final sets above
+    // MG_SEL_SMALL): continuation rounds of passes + stand-alone final sorts
     for (int round = 0; round < 20; round++) {
         bool again = false;
         for (size_t j = 0; j < seloff.size() && !again; j++) {
@@ -792,7 +804,7 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
             if (on == 0xFFFFFFFFu) again = true;
         }
         if (!again) break;
-        mgk_select(st, (const SelJob *)(UP + up_sel), UP + up_selout, (uint32_t)seljobs.size(), max_selm, MG_SEL_PASSES);
+        mgk_select(st, (const SelJob *)(UP + up_sel), UP + up_selout, (uint32_t)seljobs.size(), max_selm, MG_SEL_PASSES, 1);
         HIPCHK(hipMemcpyAsync(c->pin_out, R, res_bytes, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
     }
@@ -810,6 +822,7 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
     }
 
     // ---------------- decode ----------------
+    const double t_waited = wall_ms();
     memset(c->stage_bytes, 0, sizeof(c->stage_bytes));
     int worst = MGPU_OK;
     for (int i = 0; i < n; i++) {
@@ -888,6 +901,8 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
         if (h.k) c->stage_bytes[6] += 16 * M * (M > MG_SEL_SMALL ? 2 : 1);
     }
     c->stage_bytes[0] = up_bytes; c->stage_bytes[7] = res_bytes;
+    c->host_ms[0] = (float)(t_lowered - t_begin); c->host_ms[1] = (float)(t_waited - t_lowered);
+    c->host_ms[2] = (float)(wall_ms() - t_waited);
     return worst;
 }
 

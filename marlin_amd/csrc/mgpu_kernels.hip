@@ -423,14 +423,33 @@ __global__ __launch_bounds__(MG_BLOCK) void k_rank_tile(const SqDev *sqs, const 
             s_e0[tid] = e0; s_len[tid] = len; s_cnt[tid] = 0;
             __syncthreads();
             const uint2 *dw = sq.sh.dw;
-            for (uint32_t d = grp; d < MG_BLOCK; d += MG_BLOCK / 16) {
+            // group g owns documents 16g .. 16g+15 of the tile; lane gl reads entry gl of each.  The 16
+            // loads are issued back to back (one memory latency for the whole group step, not 16).
+            uint2 wi[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint32_t d = grp * 16 + k;
+                wi[k] = (gl < s_len[d]) ? dw[s_e0[d] + gl] : make_uint2(0u, 0u);
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint32_t d = grp * 16 + k;
+                uint32_t val;
+                if (wi[k].x && probe_wid(htab, hmask, wi[k].x, val)) {
+                    const uint32_t r = atomicAdd(&s_cnt[d], 1u);
+                    if (r < MG_MCAP) s_match[d * MG_MCAP + r] = make_uint2(val, wi[k].y);
+                }
+            }
+            // documents with more than 16 distinct words: the rest of their runs
+            for (int k = 0; k < 16; k++) {
+                const uint32_t d = grp * 16 + k;
                 const uint32_t len_d = s_len[d], e0_d = s_e0[d];
-                for (uint32_t j = gl; j < len_d; j += 16) {
-                    const uint2 wi = dw[e0_d + j];
+                for (uint32_t j = 16 + gl; j < len_d; j += 16) {
+                    const uint2 w2 = dw[e0_d + j];
                     uint32_t val;
-                    if (probe_wid(htab, hmask, wi.x, val)) {
+                    if (probe_wid(htab, hmask, w2.x, val)) {
                         const uint32_t r = atomicAdd(&s_cnt[d], 1u);
-                        if (r < MG_MCAP) s_match[d * MG_MCAP + r] = make_uint2(val, wi.y);
+                        if (r < MG_MCAP) s_match[d * MG_MCAP + r] = make_uint2(val, w2.y);
                     }
                 }
             }
@@ -707,15 +726,87 @@ __device__ __forceinline__ uint32_t sel_nblocks(uint32_t nin, uint32_t gdim) {
     return nch < gdim ? nch : gdim;
 }
 
+struct SelOut { u64 *out_hi, *out_lo; uint32_t *out_pl; const uint32_t *payload; };
+
+// Final step of a selection, run by one workgroup: gather the winners the passes found and the
+// last candidate list with the last decision applied, bitonic-sort them by (hi, lo, idx) in LDS and
+// emit the first k.  s_cnt: two LDS words.
+template <int CAP>
+__device__ __forceinline__ void sel_final(const SelJob &job, const SelOut &out, uint32_t pass, uint32_t nin, uint32_t nwin,
+                                          uint32_t dstar, const uint32_t *rin, const uint32_t *pprev, int nprev,
+                                          u64 *s_hi, u64 *s_lo, uint32_t *s_ix, uint32_t *s_cnt) {
+    if (threadIdx.x == 0) { s_cnt[0] = 0; s_cnt[1] = 0; }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nwin; i += MG_BLOCK) {
+        const uint32_t idx = job.out_idx[i];
+        const uint32_t p = atomicAdd(&s_cnt[0], 1u);
+        if (p < CAP) { s_hi[p] = job.key_hi[idx]; s_lo[p] = job.key_lo[idx]; s_ix[p] = idx; }
+    }
+    for (uint32_t i0 = threadIdx.x; i0 < nin; i0 += 4 * MG_BLOCK) {
+        uint32_t idxs[4]; u64 his[4], los[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint32_t i = i0 + u * MG_BLOCK; idxs[u] = (i < nin) ? (rin ? rin[i] : i) : 0xFFFFFFFFu; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const bool v = idxs[u] != 0xFFFFFFFFu;
+            his[u] = v ? job.key_hi[idxs[u]] : 0; los[u] = v ? job.key_lo[idxs[u]] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            bool take = idxs[u] != 0xFFFFFFFFu;
+            if (take && pass > 0) take = digit_of(his[u], los[u], idxs[u], pprev, nprev) <= dstar;
+            if (take) {
+                const uint32_t p = atomicAdd(&s_cnt[0], 1u);
+                if (p < CAP) { s_hi[p] = his[u]; s_lo[p] = los[u]; s_ix[p] = idxs[u]; }
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t n = s_cnt[0] < (uint32_t)CAP ? s_cnt[0] : (uint32_t)CAP;
+    uint32_t np2 = 1; while (np2 < n) np2 <<= 1;
+    for (uint32_t i = n + threadIdx.x; i < np2; i += MG_BLOCK) { s_hi[i] = ~0ull; s_lo[i] = ~0ull; s_ix[i] = 0xFFFFFFFFu; }
+    __syncthreads();
+    for (uint32_t k = 2; k <= np2; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < np2; i += MG_BLOCK) {
+                const uint32_t l = i ^ j;
+                if (l > i) {
+                    const bool up = (i & k) == 0;
+                    const u64 ah = s_hi[i], al = s_lo[i], bh = s_hi[l], bl = s_lo[l];
+                    const uint32_t ai = s_ix[i], bi = s_ix[l];
+                    const bool gt = (ah > bh) || (ah == bh && (al > bl || (al == bl && ai > bi)));
+                    if (gt == up) { s_hi[i] = bh; s_lo[i] = bl; s_ix[i] = bi; s_hi[l] = ah; s_lo[l] = al; s_ix[l] = ai; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const uint32_t kk = job.k < n ? job.k : n;
+    for (uint32_t i = threadIdx.x; i < kk; i += MG_BLOCK) {
+        if (job.skip_ones && s_hi[i] == ~0ull) continue;
+        out.out_hi[i] = s_hi[i]; out.out_lo[i] = s_lo[i];
+        out.out_pl[i] = out.payload ? out.payload[s_ix[i]] : s_ix[i];
+        atomicAdd(&s_cnt[1], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *job.out_n = s_cnt[1];
+}
+
 // One pass = filter the candidate list by the previous digit decision (winners below it go to the
 // output, the digit's own bucket stays a candidate) and histogram the survivors on the next digit;
 // the last workgroup to finish picks the bucket holding the k-th key.  Lists that fit one
 // workgroup (the common case: a shard's hits for one query) never come back to the host: that
-// workgroup keeps iterating passes in LDS until the answer fits the final sort.
-__global__ __launch_bounds__(MG_BLOCK) void k_select_pass(const SelJob *jobs) {
+// workgroup keeps iterating passes in LDS until the answer fits the final sort, and when that
+// sort is small it does it on the spot (SEL_DONE = 2): no further launch touches the job.
+__global__ __launch_bounds__(MG_BLOCK) void k_select_pass(const SelJob *jobs, const SelOut *outs) {
     const SelJob job = jobs[blockIdx.y];
     uint32_t *ctl = job.ctl;
     const uint32_t M = *job.m_ptr;
+    __shared__ u64 s_fhi[SEL_SMALL_CAP], s_flo[SEL_SMALL_CAP];
+    __shared__ uint32_t s_fix[SEL_SMALL_CAP], s_fcnt[2];
+    // until a final sort has run the host must see "not finished"
+    if (blockIdx.x == 0 && threadIdx.x == 0 &&
+        __hip_atomic_load(&ctl[SEL_DONE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 2u) *job.out_n = 0xFFFFFFFFu;
     __shared__ uint32_t hist[MG_SEL_BINS];
     __shared__ uint32_t s_ctl[SEL_WORDS];
     __shared__ uint32_t s_scan[8];
@@ -735,7 +826,10 @@ __global__ __launch_bounds__(MG_BLOCK) void k_select_pass(const SelJob *jobs) {
         const uint32_t pass = s_ctl[SEL_PASS];
         const uint32_t nin = (pass == 0) ? M : s_ctl[SEL_NIN];
         if (pass == 0 && (M <= SEL_SMALL_CAP || job.k >= M)) {
-            if (blockIdx.x == 0 && threadIdx.x == 0) { ctl[SEL_NIN] = M; ctl[SEL_KREM] = job.k; ctl[SEL_NFIN] = M; ctl[SEL_DONE] = 1; }
+            if (blockIdx.x != 0) return;
+            const bool small = M <= SEL_SMALL_CAP;
+            if (threadIdx.x == 0) { ctl[SEL_NIN] = M; ctl[SEL_KREM] = job.k; ctl[SEL_NFIN] = M; ctl[SEL_DONE] = small ? 2u : 1u; }
+            if (small) sel_final<SEL_SMALL_CAP>(job, outs[blockIdx.y], 0, M, 0, 0, nullptr, s_pcur, 0, s_fhi, s_flo, s_fix, s_fcnt);
             return;
         }
         const uint32_t nb = sel_nblocks(nin, gridDim.x);
@@ -753,8 +847,8 @@ __global__ __launch_bounds__(MG_BLOCK) void k_select_pass(const SelJob *jobs) {
         }
         const uint32_t dstar = s_ctl[SEL_DSTAR];
         const uint32_t buf = s_ctl[SEL_BUF];
-        const uint32_t *rin = (pass <= 1) ? nullptr : job.cand[buf];
-        uint32_t *rout = job.cand[buf ^ (pass <= 1 ? 0u : 1u)];
+        const uint32_t *rin = (pass <= 1) ? nullptr : (buf ? job.cand[1] : job.cand[0]);
+        uint32_t *rout = ((buf ^ (pass <= 1 ? 0u : 1u)) & 1u) ? job.cand[1] : job.cand[0];
         uint32_t *win = job.out_idx;        // winners accumulate in the output buffer, sorted at the end
         __syncthreads();
         const int nprev = (int)s_nprev, ncur = (int)s_ncur;
@@ -762,20 +856,26 @@ __global__ __launch_bounds__(MG_BLOCK) void k_select_pass(const SelJob *jobs) {
 
         const uint32_t nch = (nin + SEL_CHUNK - 1) / SEL_CHUNK;
         for (uint32_t ch = vbid; ch < nch; ch += nb) {
-#pragma unroll 2
+            // all loads of the chunk first (8 candidates per lane in flight), then the decisions
+            uint32_t idxs[SEL_ITEMS]; u64 his[SEL_ITEMS], los[SEL_ITEMS];
+#pragma unroll
             for (int it = 0; it < SEL_ITEMS; it++) {
                 const uint32_t i = ch * SEL_CHUNK + it * MG_BLOCK + threadIdx.x;
-                bool keep = false, winner = false;
-                uint32_t idx = 0; u64 hi = 0, lo = 0;
-                if (i < nin) {
-                    idx = rin ? rin[i] : i;
-                    hi = job.key_hi[idx]; lo = job.key_lo[idx];
-                    keep = true;
-                    if (pass > 0) {
-                        const uint32_t dp = digit_of(hi, lo, idx, s_pprev, nprev);
-                        if (dp < dstar) { winner = true; keep = false; }
-                        else if (dp > dstar) keep = false;
-                    }
+                idxs[it] = (i < nin) ? (rin ? rin[i] : i) : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (int it = 0; it < SEL_ITEMS; it++) {
+                const bool v = idxs[it] != 0xFFFFFFFFu;
+                his[it] = v ? job.key_hi[idxs[it]] : 0; los[it] = v ? job.key_lo[idxs[it]] : 0;
+            }
+#pragma unroll
+            for (int it = 0; it < SEL_ITEMS; it++) {
+                const uint32_t idx = idxs[it]; const u64 hi = his[it], lo = los[it];
+                bool keep = idx != 0xFFFFFFFFu, winner = false;
+                if (keep && pass > 0) {
+                    const uint32_t dp = digit_of(hi, lo, idx, s_pprev, nprev);
+                    if (dp < dstar) { winner = true; keep = false; }
+                    else if (dp > dstar) keep = false;
                 }
                 if (pass > 0) {
                     // wave-aggregated appends
@@ -842,7 +942,8 @@ __global__ __launch_bounds__(MG_BLOCK) void k_select_pass(const SelJob *jobs) {
             }
         }
         __syncthreads();
-        bool done = false, go_on = false;
+        bool done = false, go_on = false, fused = false;
+        uint32_t d_fin = 0, newbuf = buf;
         {
             uint32_t d = s_dstar, cum = s_cum;
             if (d >= nbins) { d = nbins - 1; cum = nkept; }
@@ -850,6 +951,9 @@ __global__ __launch_bounds__(MG_BLOCK) void k_select_pass(const SelJob *jobs) {
             if (pass > 0 && nkept <= MG_SEL_FINAL) done = true;
             else if (nkept <= SEL_SOLO_CHUNKS * SEL_CHUNK && nwin_total + cum <= MG_SEL_FINAL) done = true;
             go_on = !done && sel_nblocks(nkept, gridDim.x) == 1;
+            fused = done && nkept <= SEL_SOLO_CHUNKS * SEL_CHUNK && nwin_total + cum <= SEL_SMALL_CAP;
+            d_fin = d;
+            if (pass >= 1) newbuf = buf ^ (pass == 1 ? 0u : 1u);
             if (threadIdx.x == 0) {
                 ctl[SEL_DSTAR] = d;
                 ctl[SEL_BPREV] = bitpos;
@@ -861,10 +965,18 @@ __global__ __launch_bounds__(MG_BLOCK) void k_select_pass(const SelJob *jobs) {
                 ctl[SEL_TICKET] = 0;
                 ctl[SEL_NPREV] = (uint32_t)ncur;
                 ctl[SEL_NFIN] = nwin_total + cum;
-                if (pass >= 1) ctl[SEL_BUF] = buf ^ (pass == 1 ? 0u : 1u);
+                ctl[SEL_BUF] = newbuf;
                 ctl[SEL_PASS] = pass + 1;
-                if (done) ctl[SEL_DONE] = 1;
+                if (done) ctl[SEL_DONE] = fused ? 2u : 1u;
             }
+        }
+        if (fused) {
+            // this workgroup is the only one left on the job: sort and emit right here
+            __threadfence();
+            __syncthreads();
+            sel_final<SEL_SMALL_CAP>(job, outs[blockIdx.y], pass + 1, nkept, nwin_total, d_fin,
+                                     (pass + 1 <= 1) ? nullptr : (newbuf ? job.cand[1] : job.cand[0]), s_pcur, ncur, s_fhi, s_flo, s_fix, s_fcnt);
+            return;
         }
         if (!go_on) return;
         // next pass in this launch: make this pass's list and control words visible to the whole workgroup
@@ -873,89 +985,32 @@ __global__ __launch_bounds__(MG_BLOCK) void k_select_pass(const SelJob *jobs) {
     }
 }
 
-struct SelOut { u64 *out_hi, *out_lo; uint32_t *out_pl; const uint32_t *payload; };
-
-// final stage: one workgroup per job sorts winners + remaining candidates and emits the top k.
-// Two sizes of the same kernel: jobs whose final set fits SEL_SMALL_CAP use a 10 KiB LDS variant
-// (many per CU), the rest the SEL_BIG_CAP one.
+// final stage for the jobs the pass kernel did not finish itself (large final sets, or lists that
+// needed several workgroups): one workgroup per job.  Two sizes of the same kernel.
 template <int CAP, int LO>
 __global__ __launch_bounds__(MG_BLOCK) void k_select_final(const SelJob *jobs, const SelOut *outs) {
     const SelJob job = jobs[blockIdx.x];
-    const SelOut out = outs[blockIdx.x];
     const uint32_t *ctl = job.ctl;
     const uint32_t M = *job.m_ptr;
     __shared__ u64 s_hi[CAP];
     __shared__ u64 s_lo[CAP];
     __shared__ uint32_t s_ix[CAP];
-    __shared__ uint32_t s_n;
-    if (!ctl[SEL_DONE]) { if (LO == 0 && threadIdx.x == 0) *job.out_n = 0xFFFFFFFFu; return; }   // host launches more passes
+    __shared__ uint32_t s_cnt[2];
+    __shared__ uint32_t s_pprev[MG_SEL_DIGIT], s_nprev;
+    const uint32_t done = ctl[SEL_DONE];
+    if (done != 1u) return;                                      // 0: the host launches more passes; 2: already emitted
     const uint32_t nfin = ctl[SEL_NFIN];
     if (nfin > (uint32_t)CAP || nfin < (uint32_t)LO) return;     // the other variant's job
     const uint32_t pass = ctl[SEL_PASS];
-    const uint32_t nin = ctl[SEL_NIN];
-    const uint32_t nwin = ctl[SEL_NWIN];
     u64 mhi, mlo; uint32_t midx;
     job_masks(job, M, mhi, mlo, midx);
-    __shared__ uint32_t s_pprev[MG_SEL_DIGIT], s_nprev;
-    const uint32_t dstar = ctl[SEL_DSTAR];
-    const uint32_t *rin = (pass <= 1) ? nullptr : job.cand[ctl[SEL_BUF]];
     if (threadIdx.x == 0) {
-        s_n = 0;
         uint32_t dummy;
         s_nprev = (pass > 0) ? (uint32_t)digit_bits(mhi, mlo, midx, ctl[SEL_BPREV], s_pprev, &dummy) : 0u;
     }
     __syncthreads();
-    const int nprev = (int)s_nprev;
-    // winners found by the passes
-    for (uint32_t i = threadIdx.x; i < nwin; i += MG_BLOCK) {
-        const uint32_t idx = job.out_idx[i];
-        const uint32_t p = atomicAdd(&s_n, 1u);
-        if (p < CAP) { s_hi[p] = job.key_hi[idx]; s_lo[p] = job.key_lo[idx]; s_ix[p] = idx; }
-    }
-    // the last candidate list, with the last decision applied
-    for (uint32_t i = threadIdx.x; i < nin; i += MG_BLOCK) {
-        const uint32_t idx = rin ? rin[i] : i;
-        const u64 hi = job.key_hi[idx], lo = job.key_lo[idx];
-        bool take = true;
-        if (pass > 0) take = digit_of(hi, lo, idx, s_pprev, nprev) <= dstar;
-        if (take) {
-            const uint32_t p = atomicAdd(&s_n, 1u);
-            if (p < CAP) { s_hi[p] = hi; s_lo[p] = lo; s_ix[p] = idx; }
-        }
-    }
-    __syncthreads();
-    uint32_t n = s_n < CAP ? s_n : CAP;
-    uint32_t np2 = 1; while (np2 < n) np2 <<= 1;
-    for (uint32_t i = n + threadIdx.x; i < np2; i += MG_BLOCK) { s_hi[i] = ~0ull; s_lo[i] = ~0ull; s_ix[i] = 0xFFFFFFFFu; }
-    __syncthreads();
-    // bitonic sort ascending by (hi, lo, idx)
-    for (uint32_t k = 2; k <= np2; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = threadIdx.x; i < np2; i += MG_BLOCK) {
-                const uint32_t l = i ^ j;
-                if (l > i) {
-                    const bool up = (i & k) == 0;
-                    const u64 ah = s_hi[i], al = s_lo[i], bh = s_hi[l], bl = s_lo[l];
-                    const uint32_t ai = s_ix[i], bi = s_ix[l];
-                    const bool gt = (ah > bh) || (ah == bh && (al > bl || (al == bl && ai > bi)));
-                    if (gt == up) { s_hi[i] = bh; s_lo[i] = bl; s_ix[i] = bi; s_hi[l] = ah; s_lo[l] = al; s_ix[l] = ai; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-    uint32_t kk = job.k < n ? job.k : n;
-    __shared__ uint32_t s_cnt;
-    if (threadIdx.x == 0) s_cnt = 0;
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < kk; i += MG_BLOCK) {
-        if (job.skip_ones && s_hi[i] == ~0ull) continue;
-        out.out_hi[i] = s_hi[i]; out.out_lo[i] = s_lo[i];
-        out.out_pl[i] = out.payload ? out.payload[s_ix[i]] : s_ix[i];
-        atomicAdd(&s_cnt, 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) *job.out_n = s_cnt;
+    sel_final<CAP>(job, outs[blockIdx.x], pass, ctl[SEL_NIN], ctl[SEL_NWIN], ctl[SEL_DSTAR],
+                   (pass <= 1) ? nullptr : (ctl[SEL_BUF] ? job.cand[1] : job.cand[0]), s_pprev, (int)s_nprev, s_hi, s_lo, s_ix, s_cnt);
 }
 
 // ------------------------------------------------------------------ primitives for the parity tests
@@ -1020,7 +1075,9 @@ void mgk_card(hipStream_t st, const void *jobs, uint32_t njobs, uint32_t max_n) 
     if (gx > cap) gx = cap; if (!gx) gx = 1;
     hipLaunchKernelGGL(k_card, dim3(gx, njobs), dim3(MG_BLOCK), 0, st, (const CardJob *)jobs);
 }
-void mgk_select(hipStream_t st, const SelJob *jobs, const void *outs, uint32_t njobs, uint32_t max_m, int passes) {
+// `finals` = 0: only the pass launches (jobs that fit one workgroup finish inside them);
+// 1: also the stand-alone final sorts, for the continuation rounds of larger jobs.
+void mgk_select(hipStream_t st, const SelJob *jobs, const void *outs, uint32_t njobs, uint32_t max_m, int passes, int finals) {
     if (!njobs) return;
     // enough workgroups to fill the chip, never one per chunk of the largest possible list:
     // workgroups stride over chunks, and most jobs end up in a single workgroup anyway
@@ -1029,7 +1086,8 @@ void mgk_select(hipStream_t st, const SelJob *jobs, const void *outs, uint32_t n
     if (cap < 4) cap = 4;
     if (gx <= SEL_SOLO_CHUNKS) gx = 1; else if (gx > cap) gx = cap;
     for (int p = 0; p < passes; p++)
-        hipLaunchKernelGGL(k_select_pass, dim3(gx, njobs), dim3(MG_BLOCK), 0, st, jobs);
+        hipLaunchKernelGGL(k_select_pass, dim3(gx, njobs), dim3(MG_BLOCK), 0, st, jobs, (const SelOut *)outs);
+    if (!finals) return;
     hipLaunchKernelGGL((k_select_final<SEL_SMALL_CAP, 0>), dim3(njobs), dim3(MG_BLOCK), 0, st, jobs, (const SelOut *)outs);
     hipLaunchKernelGGL((k_select_final<SEL_BIG_CAP, SEL_SMALL_CAP + 1>), dim3(njobs), dim3(MG_BLOCK), 0, st, jobs, (const SelOut *)outs);
 }

@@ -51,5 +51,4 @@ class ShardGather:
         return sq
 
     def free(self, sq):
-        for i in range(len(sq)):
-            self.lib.m_sqresult_free(C.byref(sq[i]))
+        self.lib.m_sqresult_free_batch(sq, len(sq))

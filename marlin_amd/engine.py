@@ -159,8 +159,7 @@ class GpuEngine:
         self.lib.msq_prepared_free(prep[0])
 
     def free_raw(self, outs):
-        for i in range(len(outs)):
-            self.lib.m_sqresult_free(C.byref(outs[i]))
+        self.lib.m_sqresult_free_batch(outs, len(outs))
 
     def search(self, pqs, capture=0):
         """list of parsed queries -> list of assembled result dicts"""
@@ -185,5 +184,7 @@ class GpuEngine:
         self.lib.mgpu_last_timing(self.ctx, C.byref(tot), st)
         by = (C.c_uint64 * 8)()
         self.lib.mgpu_last_bytes(self.ctx, by)
-        return {"total_ms": tot.value,
+        hm = (C.c_float * 3)()
+        self.lib.mgpu_last_host_timing(self.ctx, hm)
+        return {"total_ms": tot.value, "host_ms": {"lower": hm[0], "launch+wait": hm[1], "decode": hm[2]},
                 "stages": {self.lib.mgpu_stage_name(i).decode(): {"ms": st[i], "bytes": by[i]} for i in range(8)}}

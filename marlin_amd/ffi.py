@@ -147,6 +147,7 @@ def load():
         "m_form_result": (None, [C.POINTER(Query), C.POINTER(SqResult), ci, C.POINTER(Result)]),
         "m_result_free": (None, [C.POINTER(Result)]),
         "m_sqresult_free": (None, [C.POINTER(SqResult)]),
+        "m_sqresult_free_batch": (None, [C.POINTER(SqResult), ci]),
         "mmirror_create": (ci, [vp, ci, C.POINTER(vp)]),
         "mmirror_destroy": (None, [vp]),
         "msq_set_plan_threads": (None, [ci]),
@@ -166,6 +167,7 @@ def load():
         "mgpu_ctx_destroy": (None, [vp]),
         "mgpu_ctx_set_profiling": (None, [vp, ci]),
         "mgpu_last_timing": (ci, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+        "mgpu_last_host_timing": (ci, [vp, C.POINTER(C.c_float)]),
         "mgpu_last_bytes": (ci, [vp, C.POINTER(C.c_uint64)]),
         "mgpu_stage_name": (C.c_char_p, [ci]),
         "mgpu_shard_bytes": (C.c_uint64, [vp]),

@@ -160,6 +160,7 @@ typedef struct m_sqresult {
 } m_sqresult_t;
 
 void m_sqresult_free(m_sqresult_t *r);
+void m_sqresult_free_batch(m_sqresult_t *rs, int n);
 
 #ifdef __cplusplus
 }

@@ -404,6 +404,8 @@ void m_slot_unpack(const uint8_t *buf, int k, int num_facets, int fmax, int num_
     for (int a = 0; a < num_aggs; a++) { memcpy(&out->aggs[a], p, sizeof(m_agg_t)); p += sizeof(m_agg_t); }
 }
 
+void m_sqresult_free_batch(m_sqresult_t *rs, int n) { for (int i = 0; i < n; i++) m_sqresult_free(&rs[i]); }
+
 /* pack / unpack / merge whole batches (one call per step from the launcher) */
 void m_slot_pack_batch(const m_sqresult_t *rs, int n, int k, int num_facets, int fmax, int num_aggs, uint8_t *buf) {
     size_t sb = m_slot_bytes(k, num_facets, fmax, num_aggs);
