@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="queries per step")
     ap.add_argument("--cpu-queries", type=int, default=4)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--inflight", type=int, default=4, help="batches kept in flight per GPU (host threads x contexts)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -108,7 +109,7 @@ def main():
     ix = Index.from_shards({}, shards, ["str"], ["num", "price"], ["flag"], ["cat", "hc"])
     t_build = time.time() - t0
     t0 = time.time()
-    eng = GpuEngine(ix, device=local_rank)
+    eng = GpuEngine(ix, device=local_rank, num_ctx=max(1, args.inflight))
     t_mirror = time.time() - t0
     lib.msq_set_plan_threads(min(16, max(1, (os.cpu_count() or 8) // max(world, 1))))
     mirror_bytes = sum(lib.mgpu_shard_bytes(lib.mmirror_gpu(m)) for m in eng.mirrors)
@@ -134,34 +135,70 @@ def main():
     prepared = [eng.prepare(batch_queries(j)) for j in range(nbatches)]
     t_prepare = time.time() - t0
 
-    def run_step(step):
+    F = max(1, args.inflight)
+    order = threading.Condition()
+    gather_turn = [0]
+
+    def run_step(step, slot=0, seq=None):
+        """one batch: GPU execute_squery for every (query, shard) + the form_result merge.  With
+        --gpus > 1 the cross-rank gather of step `seq` waits for its turn, so every rank issues its
+        collectives in the same order whatever the host threads do."""
         prep = prepared[step % nbatches]
         pqs = prep[2]
         qarr = (C.POINTER(ffi.Query) * B)(*[p.q for p in pqs])
-        outs = eng.execute_prepared(prep)
+        outs = eng.execute_prepared(prep, slot)
         hits = 0
         if world == 1:
             hits = lib.m_form_result_batch(qarr, outs, B, local, None, 0)
         else:
-            sq = gather.gather(outs)                 # one RCCL all_gather of fixed-size result slots
+            with order:
+                while seq is not None and gather_turn[0] != seq:
+                    if gather_turn[0] < 0:
+                        raise RuntimeError("another host thread failed")
+                    order.wait()
+                sq = gather.gather(outs)             # one RCCL all_gather of fixed-size result slots
+                gather_turn[0] += 1
+                order.notify_all()
             if sq is not None:
                 hits = lib.m_form_result_batch(qarr, sq, B, TOTAL_SHARDS, None, 0)
                 gather.free(sq)
         eng.free_raw(outs)
         return hits
 
+    def run_steps(first, count):
+        """`count` steps with up to F batches in flight (one host thread and one context each)"""
+        gather_turn[0] = 0
+        hits = [0] * F
+        err = []
+
+        def worker(t):
+            try:
+                for i in range(t, count, F):
+                    hits[t] += run_step(first + i, t, i)
+            except BaseException as e:          # surface failures instead of hanging the other thread
+                err.append(e)
+                with order:
+                    gather_turn[0] = -1
+                    order.notify_all()
+        if F == 1:
+            worker(0)
+        else:
+            th = [threading.Thread(target=worker, args=(t,)) for t in range(F)]
+            [t.start() for t in th]
+            [t.join() for t in th]
+        if err:
+            raise err[0]
+        return sum(hits)
+
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for s in range(args.warmup):
-        run_step(s)
+    run_steps(0, args.warmup)
     barrier()
     t0 = time.perf_counter()
-    total_hits = 0
-    for s in range(args.steps):
-        total_hits += run_step(args.warmup + s)
+    total_hits = run_steps(args.warmup, args.steps)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -244,7 +281,7 @@ def main():
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "configs[2]: %d docs Zipf corpus, %d shards, 3-word typo+prefix query, 2 facet fields, "
                                    "rankBy num desc, top-10, fullScan" % (args.docs, TOTAL_SHARDS),
-                       "queries_per_step": B, "shards_per_gpu": local, "vocab": VOCAB,
+                       "queries_per_step": B, "batches_in_flight": F, "shards_per_gpu": local, "vocab": VOCAB,
                        "mean_hits_per_query": round(total_hits / max(1, args.steps * B), 1)},
             "roofline": roof, "cpu_baseline": cpu,
             "latency_ms": {"p50": round(lat[len(lat) // 2], 3), "p99": round(lat[int(len(lat) * 0.99)], 3),

@@ -22,6 +22,13 @@ __device__ __forceinline__ uint32_t wave_sum32(uint32_t v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// ---- optional phase clocks (mgpu_debug_phases): cycles summed per phase over the active workgroups
+__device__ int mg_dbg_on = 0;
+__device__ unsigned long long mg_dbg_acc[16];
+#define DBG_T(var) const long long var = mg_dbg_on ? (long long)wall_clock64() : 0
+#define DBG_ADD(slot, a, b) do { if (mg_dbg_on && threadIdx.x == 0) atomicAdd(&mg_dbg_acc[slot], (unsigned long long)((b) - (a))); } while (0)
+#define DBG_CNT(slot) do { if (mg_dbg_on && threadIdx.x == 0) atomicAdd(&mg_dbg_acc[slot], 1ull); } while (0)
+
 // exclusive scan of one u32 per thread over a 256-thread block; returns the block total in *total
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *total, uint32_t *lds /* >= 8 */) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -401,6 +408,7 @@ __global__ __launch_bounds__(MG_BLOCK) void k_rank_tile(const SqDev *sqs, const 
     const uint32_t tid = threadIdx.x;
     const uint32_t grp = tid >> 4, gl = tid & 15;
     for (uint32_t w = blockIdx.x; w < ntiles; w += gridDim.x) {
+        DBG_T(t0);
         const uint2 item = tile_list[w];
         const SqDev &sq = sqs[item.x];
         const int do_rank = sq.do_rank;
@@ -422,6 +430,7 @@ __global__ __launch_bounds__(MG_BLOCK) void k_rank_tile(const SqDev *sqs, const 
             if (valid) { e0 = sq.sh.dw_off[docid]; len = sq.sh.dw_off[docid + 1] - e0; pbase = sq.sh.pp_off[docid]; }
             s_e0[tid] = e0; s_len[tid] = len; s_cnt[tid] = 0;
             __syncthreads();
+            DBG_T(t1); DBG_ADD(0, t0, t1);
             const uint2 *dw = sq.sh.dw;
             // group g owns documents 16g .. 16g+15 of the tile; lane gl reads entry gl of each.  The 16
             // loads are issued back to back (one memory latency for the whole group step, not 16).
@@ -454,7 +463,9 @@ __global__ __launch_bounds__(MG_BLOCK) void k_rank_tile(const SqDev *sqs, const 
                 }
             }
             __syncthreads();
+            DBG_T(t2); DBG_ADD(1, t1, t2);
         }
+        DBG_T(t3);
         u64 a = 0, b = 0, na = 0, nb = 0;
         if (valid) {
             RankOut ro = {0, 0, 0, 0, 0};
@@ -483,6 +494,7 @@ __global__ __launch_bounds__(MG_BLOCK) void k_rank_tile(const SqDev *sqs, const 
         }
         or_key_bits(sq, a, b, na, nb);
         __syncthreads();                             // LDS is reused by the next work item
+        DBG_T(t4); DBG_ADD(2, t3, t4); DBG_CNT(3);
     }
 }
 
@@ -804,6 +816,7 @@ __global__ __launch_bounds__(MG_BLOCK) void k_select_pass(const SelJob *jobs, co
     const uint32_t M = *job.m_ptr;
     __shared__ u64 s_fhi[SEL_SMALL_CAP], s_flo[SEL_SMALL_CAP];
     __shared__ uint32_t s_fix[SEL_SMALL_CAP], s_fcnt[2];
+    DBG_T(ts0);
     // until a final sort has run the host must see "not finished"
     if (blockIdx.x == 0 && threadIdx.x == 0 &&
         __hip_atomic_load(&ctl[SEL_DONE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 2u) *job.out_n = 0xFFFFFFFFu;
@@ -853,6 +866,7 @@ __global__ __launch_bounds__(MG_BLOCK) void k_select_pass(const SelJob *jobs, co
         __syncthreads();
         const int nprev = (int)s_nprev, ncur = (int)s_ncur;
         const uint32_t next_bitpos = s_nextbit;
+        DBG_T(ts1); DBG_ADD(4, ts0, ts1);
 
         const uint32_t nch = (nin + SEL_CHUNK - 1) / SEL_CHUNK;
         for (uint32_t ch = vbid; ch < nch; ch += nb) {
@@ -899,6 +913,7 @@ __global__ __launch_bounds__(MG_BLOCK) void k_select_pass(const SelJob *jobs, co
             }
         }
         __syncthreads();
+        DBG_T(ts2); DBG_ADD(5, ts1, ts2);
         uint32_t nwin_total, nkept;
         if (!solo) {
             for (uint32_t i = threadIdx.x; i < MG_SEL_BINS; i += MG_BLOCK) {
@@ -970,12 +985,14 @@ __global__ __launch_bounds__(MG_BLOCK) void k_select_pass(const SelJob *jobs, co
                 if (done) ctl[SEL_DONE] = fused ? 2u : 1u;
             }
         }
+        DBG_T(ts3); DBG_ADD(6, ts2, ts3);
         if (fused) {
             // this workgroup is the only one left on the job: sort and emit right here
             __threadfence();
             __syncthreads();
             sel_final<SEL_SMALL_CAP>(job, outs[blockIdx.y], pass + 1, nkept, nwin_total, d_fin,
                                      (pass + 1 <= 1) ? nullptr : (newbuf ? job.cand[1] : job.cand[0]), s_pcur, ncur, s_fhi, s_flo, s_fix, s_fcnt);
+            DBG_T(ts4); DBG_ADD(7, ts3, ts4); DBG_CNT(8);
             return;
         }
         if (!go_on) return;
@@ -1030,6 +1047,14 @@ __global__ __launch_bounds__(MG_BLOCK) void k_row_op(const u64 *a, const u64 *b,
 
 // ------------------------------------------------------------------ launch wrappers (called from mgpu_api.hip)
 extern "C" {
+// phase clocks: enable, and read + reset the 16 accumulators (100 MHz wall_clock64 ticks)
+int mgk_debug_phases(int on, unsigned long long *out16) {
+    unsigned long long z[16] = {0};
+    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(mg_dbg_acc), sizeof(z)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(mg_dbg_acc), z, sizeof(z)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(mg_dbg_on), &on, sizeof(int)) != hipSuccess) return -1;
+    return 0;
+}
 void mgk_scatter(hipStream_t st, const ScatterItem *items, uint32_t nitems) {
     if (!nitems) return;
     uint32_t grid = nitems < 8192 ? nitems : 8192;

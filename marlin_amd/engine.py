@@ -92,16 +92,22 @@ def shard_results_to_py(index, pq, sqres):
 
 
 class GpuEngine:
-    def __init__(self, index, device=0, scratch_bytes=0):
+    def __init__(self, index, device=0, scratch_bytes=0, num_ctx=1):
+        """num_ctx > 1 creates further contexts (own stream, arena and staging buffers each) over the
+        same shard mirrors, so that several host threads can keep batches in flight on one GPU."""
         self.lib = lib = ffi.load()
         self.index = index
         self.device = device
         if lib.mgpu_device_count() <= device:
             raise GpuError("no HIP device %d visible (mgpu_device_count=%d)" % (device, lib.mgpu_device_count()))
-        self.ctx = C.c_void_p()
-        rc = lib.mgpu_ctx_create(device, scratch_bytes, C.byref(self.ctx))
-        if rc:
-            raise GpuError("mgpu_ctx_create: %d %s" % (rc, lib.mgpu_last_error().decode()))
+        self.ctxs = []
+        for _ in range(max(1, num_ctx)):
+            ctx = C.c_void_p()
+            rc = lib.mgpu_ctx_create(device, scratch_bytes, C.byref(ctx))
+            if rc:
+                raise GpuError("mgpu_ctx_create: %d %s" % (rc, lib.mgpu_last_error().decode()))
+            self.ctxs.append(ctx)
+        self.ctx = self.ctxs[0]
         self.mirrors = []
         for s in index.shards:
             m = C.c_void_p()
@@ -115,12 +121,14 @@ class GpuEngine:
         for m in self.mirrors:
             self.lib.mmirror_destroy(m)
         self.mirrors = []
-        if self.ctx:
-            self.lib.mgpu_ctx_destroy(self.ctx)
-            self.ctx = None
+        for ctx in self.ctxs:
+            self.lib.mgpu_ctx_destroy(ctx)
+        self.ctxs = []
+        self.ctx = None
 
     def set_profiling(self, on):
-        self.lib.mgpu_ctx_set_profiling(self.ctx, 1 if on else 0)
+        for ctx in self.ctxs:
+            self.lib.mgpu_ctx_set_profiling(ctx, 1 if on else 0)
 
     def execute_raw(self, pqs, capture=0):
         """returns a ctypes SqResult array of len(pqs) * num_shards (caller frees with free_raw)"""
@@ -146,10 +154,10 @@ class GpuEngine:
             raise GpuError("msq_prepare_batch: %d %s" % (rc, self.lib.mgpu_last_error().decode()))
         return (h, nq, pqs)
 
-    def execute_prepared(self, prep):
+    def execute_prepared(self, prep, slot=0):
         h, nq, _ = prep
         outs = (ffi.SqResult * (nq * self.index.num_shards))()
-        rc = self.lib.msq_execute_prepared(self.ctx, h, outs)
+        rc = self.lib.msq_execute_prepared(self.ctxs[slot], h, outs)
         if rc:
             self.free_raw(outs)
             raise GpuError("msq_execute_prepared: %d %s" % (rc, self.lib.mgpu_last_error().decode()))

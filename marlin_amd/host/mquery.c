@@ -222,6 +222,12 @@ static int cmp_fc(const void *pa, const void *pb) {
     return 0;
 }
 
+static int cmp_fc_id(const void *pa, const void *pb) {
+    const m_facet_count_t *a = pa, *b = pb;
+    if (a->facet_id != b->facet_id) return a->facet_id < b->facet_id ? -1 : 1;
+    return (int)a->shard_id - (int)b->shard_id;
+}
+
 static int cmp_u32(const void *a, const void *b) {
     uint32_t x = *(const uint32_t *)a, y = *(const uint32_t *)b;
     return x < y ? -1 : (x > y);
@@ -310,15 +316,17 @@ void m_form_result(const m_query_t *q, m_sqresult_t *sq, int num_shards, m_resul
         for (int i = 0; i < num_shards; i++) cap += sq[i].rcount[f];
         m_facet_count_t *fc = malloc((cap ? cap : 1) * sizeof(m_facet_count_t));
         int rcount = 0;
-        for (int i = 0; i < num_shards; i++) {
-            for (int j = 0; j < sq[i].rcount[f]; j++) {
-                const m_facet_count_t *ifc = &sq[i].fc[f][j];
-                int k;
-                for (k = 0; k < rcount; k++) if (fc[k].facet_id == ifc->facet_id) break;
-                if (k < rcount) fc[k].count += ifc->count;
-                else { fc[rcount] = *ifc; fc[rcount].shard_id = (uint8_t)i; rcount++; }
-            }
+        /* same sums as the reference's find-or-append walk, without its quadratic search:
+         * order by (facet id, shard), fold equal ids into the first (= lowest shard) entry */
+        for (int i = 0; i < num_shards; i++)
+            for (int j = 0; j < sq[i].rcount[f]; j++) { fc[rcount] = sq[i].fc[f][j]; fc[rcount].shard_id = (uint8_t)i; rcount++; }
+        qsort(fc, (size_t)rcount, sizeof(m_facet_count_t), cmp_fc_id);
+        int w = 0;
+        for (int k = 0; k < rcount; k++) {
+            if (w && fc[w - 1].facet_id == fc[k].facet_id) fc[w - 1].count += fc[k].count;
+            else fc[w++] = fc[k];
         }
+        rcount = w;
         qsort(fc, (size_t)rcount, sizeof(m_facet_count_t), cmp_fc);
         if (rcount > q->cfg.max_facet_results) rcount = q->cfg.max_facet_results;
         out->fc[f] = fc;

@@ -1,0 +1,31 @@
+"""diagnostic: phase clocks of the rank / select kernels on the bench workload (not part of the product)"""
+import ctypes as C, sys, os, json
+sys.argv = [sys.argv[0]]
+import bench
+from marlin_amd import ffi
+lib = ffi.load()
+gpu = C.CDLL(os.path.join(ffi.LIB_DIR, "libmarlin_gpu.so"))
+gpu.mgk_debug_phases.argtypes = [C.c_int, C.POINTER(C.c_ulonglong)]
+_orig = bench.json.dumps
+def hook(line):
+    return _orig(line)
+import torch
+torch.cuda.set_device(0)
+from marlin_amd import GpuEngine, Index
+shards = bench.build_shards(lib, 10_000_000, list(range(8)))
+ix = Index.from_shards({}, shards, ["str"], ["num", "price"], ["flag"], ["cat", "hc"])
+eng = GpuEngine(ix, device=0)
+lib.msq_set_plan_threads(16)
+pool = [ix.query(j) for j in bench.make_queries(lib, 64)]
+prep = eng.prepare(pool[:32])
+for _ in range(3):
+    eng.free_raw(eng.execute_prepared(prep))
+gpu.mgk_debug_phases(1, None)
+for _ in range(5):
+    eng.free_raw(eng.execute_prepared(prep))
+out = (C.c_ulonglong * 16)()
+gpu.mgk_debug_phases(0, out)
+v = list(out)
+tiles = max(1, v[3]); jobs = max(1, v[8])
+print("rank tiles/launch", tiles / 5, "per-tile us: setup %.2f phase1 %.2f phase2 %.2f" % (v[0] / tiles / 100, v[1] / tiles / 100, v[2] / tiles / 100))
+print("select fused jobs/launch", jobs / 5, "us per WG (all WGs incl. idle contribute to setup): setup %.2f chunks %.2f decide %.2f final %.2f" % (v[4] / jobs / 100, v[5] / jobs / 100, v[6] / jobs / 100, v[7] / jobs / 100))
