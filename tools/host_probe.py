@@ -1,5 +1,6 @@
 """diagnostic: where the host time of one bench step goes"""
 import ctypes as C, sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.argv = [sys.argv[0]]
 import bench
 from marlin_amd import ffi, GpuEngine, Index

@@ -1,5 +1,6 @@
 """diagnostic: phase clocks of the rank / select kernels on the bench workload (not part of the product)"""
 import ctypes as C, sys, os, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.argv = [sys.argv[0]]
 import bench
 from marlin_amd import ffi
