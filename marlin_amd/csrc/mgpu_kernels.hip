@@ -27,6 +27,13 @@ __device__ int mg_dbg_on = 0;
 __device__ unsigned long long mg_dbg_acc[16];
 #define DBG_T(var) const long long var = mg_dbg_on ? (long long)wall_clock64() : 0
 #define DBG_ADD(slot, a, b) do { if (mg_dbg_on && threadIdx.x == 0) atomicAdd(&mg_dbg_acc[slot], (unsigned long long)((b) - (a))); } while (0)
+#define DBG_MAX(slot, a, b, tag) do { if (mg_dbg_on && threadIdx.x == 0) atomicMax(&mg_dbg_acc[slot], ((unsigned long long)((b) - (a)) << 32) | (unsigned long long)(tag)); } while (0)
+struct DbgScope {       // records the longest lifetime of a workgroup (slot) with a tag, at every exit path
+    long long t0; int slot; unsigned tag;
+    __device__ DbgScope(int s) : t0(mg_dbg_on ? (long long)wall_clock64() : 0), slot(s), tag(0) {}
+    __device__ ~DbgScope() { if (mg_dbg_on && threadIdx.x == 0) { long long t1 = (long long)wall_clock64(); atomicMax(&mg_dbg_acc[slot], ((unsigned long long)(t1 - t0) << 32) | tag);
+        atomicMax(&mg_dbg_acc[14], ~(unsigned long long)t0); atomicMax(&mg_dbg_acc[15], (unsigned long long)t1); } }
+};
 #define DBG_CNT(slot) do { if (mg_dbg_on && threadIdx.x == 0) atomicAdd(&mg_dbg_acc[slot], 1ull); } while (0)
 
 // exclusive scan of one u32 per thread over a 256-thread block; returns the block total in *total
@@ -259,35 +266,38 @@ __device__ __forceinline__ void rank_init(RankState &s) {
     s.bestpos = 0xFFFFFFFFu; s.np = 0; s.comb = false; s.ovf = false;
 }
 
-// val = dist | mterm << 8 | exact_mask << 16 (wid table); info = the docword's position descriptor;
-// pp_doc = the document's slice of the position pool
-template <class PS>
-__device__ __forceinline__ void rank_consume(RankState &s, int nw, int nt, uint32_t val, uint32_t info,
-                                             const uint32_t *pp_doc, PS &ps) {
+// which proximity slots the positions of a word matched through term `mterm` feed
+// (rank_three_terms docrank.c:125-209, rank_many_terms docrank.c:218-328; term_to_word_idx's
+// quirk reduces to term / 2)
+__device__ __forceinline__ void rank_slots(int nw, int nt, uint32_t mterm, int &slot_a, int &slot_b, bool &keep_a) {
+    slot_b = -1; keep_a = true;
+    if (nw == 2) { slot_a = (int)mterm; keep_a = slot_a != 2; }     // the pair term only feeds best_position
+    else {
+        slot_a = (int)mterm >> 1;
+        if ((mterm & 1u) && (int)mterm != nt - 1) slot_b = slot_a + 1;
+    }
+}
+__device__ __forceinline__ uint32_t info_first_inline(uint32_t info) { return (((info >> 1) & 0xFFu) << 16) + (info >> 9); }
+
+// the order-free reductions of one matched word; val = dist | mterm << 8 | exact_mask << 16 (wid
+// table), first = (priority << 16) + position of its first occurrence
+__device__ __forceinline__ void rank_reduce(RankState &s, int nw, int nt, uint32_t val, uint32_t first) {
     s.exact_mask |= val >> 16;
     const uint32_t dist = val & 0xFF, mterm = (val >> 8) & 0xFF;
     if (dist == 0xFF) return;
-    const bool inl = info & 1u;
-    const uint32_t cnt = inl ? 1u : ((info >> 1) & 0xFFu);
-    const uint32_t poff = info >> 9;
-    const uint32_t first = inl ? ((((info >> 1) & 0xFFu) << 16) + poff) : pp_doc[poff];
     if (nw == 1) {
         // rank_single_term (docrank.c:63-112): least distance, then least (field, position)
         const u64 k = ((u64)dist << 40) | (u64)first;
         if (k < s.single_best) s.single_best = k;
         return;
     }
-    int slot_a, slot_b = -1;
     if (nw == 2) {
-        // rank_three_terms (docrank.c:125-209)
         if (mterm == 2) s.comb = true;
         else {
             const int sh8 = (int)mterm * 8;
             if (dist < ((s.typ_lo >> sh8) & 0xFF)) s.typ_lo = (s.typ_lo & ~(0xFFull << sh8)) | ((u64)dist << sh8);
         }
-        slot_a = (int)mterm;
     } else {
-        // rank_many_terms (docrank.c:218-328); term_to_word_idx's quirk reduces to term / 2
         if ((int)mterm == nt - 1) s.comb = true;
         const int widx = (int)mterm >> 1;
         {
@@ -295,19 +305,32 @@ __device__ __forceinline__ void rank_consume(RankState &s, int nw, int nt, uint3
             const int sh8 = (widx & 7) * 8;
             if (dist < ((tw >> sh8) & 0xFF)) tw = (tw & ~(0xFFull << sh8)) | ((u64)dist << sh8);
         }
-        slot_a = widx;
         if (mterm & 1u) {
             s.prox1 |= 1u << widx;
             if ((int)mterm != nt - 1) {
                 const int w1 = widx + 1;
                 u64 &tw = w1 < 8 ? s.typ_lo : s.typ_hi;
                 tw &= ~(0xFFull << ((w1 & 7) * 8));
-                slot_b = w1;
             }
         }
     }
     if (first < s.bestpos) s.bestpos = first;          // runs are sorted: the first entry is the least
-    const bool keep_a = !(nw == 2 && slot_a == 2);     // the pair term only feeds best_position
+}
+
+// serial form used by the overflow kernel: reductions + the word's (slot, position) pairs.
+// info = the docword's position descriptor; pp_doc = the document's slice of the position pool
+template <class PS>
+__device__ __forceinline__ void rank_consume(RankState &s, int nw, int nt, uint32_t val, uint32_t info,
+                                             const uint32_t *pp_doc, PS &ps) {
+    const bool inl = info & 1u;
+    const uint32_t cnt = inl ? 1u : ((info >> 1) & 0xFFu);
+    const uint32_t poff = info >> 9;
+    const bool ranked = (val & 0xFF) != 0xFF;
+    const uint32_t first = !ranked ? 0u : inl ? info_first_inline(info) : pp_doc[poff];
+    rank_reduce(s, nw, nt, val, first);
+    if (!ranked || nw == 1) return;
+    int slot_a, slot_b; bool keep_a;
+    rank_slots(nw, nt, (val >> 8) & 0xFF, slot_a, slot_b, keep_a);
     for (uint32_t j = 0; j < cnt; j++) {
         const uint32_t p = (j == 0) ? first : pp_doc[poff + j];
         if (keep_a) { if (s.np < ps.cap) ps.set(s.np++, ((uint32_t)slot_a << 24) | p); else s.ovf = true; }
@@ -364,12 +387,25 @@ __device__ __forceinline__ u64 f64_order_key(double x) {
     return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
 }
 
-__device__ __forceinline__ void build_key(const SqDev &sq, const RankOut &ro, double cmp, u64 &hi, u64 &lo) {
+// the key layout as 8 packed words {kind, bits, shift, hi}, so that it can live in registers
+struct KeyLayout { uint32_t f[8]; int n; };
+__device__ __forceinline__ KeyLayout load_key_layout(const SqDev *sp) {
+    KeyLayout k;
+    const uint32_t *w = (const uint32_t *)sp->kf;
+#pragma unroll
+    for (int i = 0; i < 8; i++) k.f[i] = w[i];
+    k.n = sp->nkf;
+    return k;
+}
+__device__ __forceinline__ void build_key(const KeyLayout &kl, const RankOut &ro, double cmp, u64 &hi, u64 &lo) {
     u128 key = 0;
-    for (int i = 0; i < sq.nkf; i++) {
-        const KeyField f = sq.kf[i];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        if (i >= kl.n) break;
+        const int kind = (int)(int8_t)(kl.f[i] & 0xFF);
+        const uint32_t shift = (kl.f[i] >> 16) & 0xFF;
         u64 v;
-        switch (f.kind) {
+        switch (kind) {
             case KF_TYPO: v = ro.typos; break;
             case KF_PROX: v = ro.prox; break;
             case KF_POS: v = ro.pos; break;
@@ -378,17 +414,17 @@ __device__ __forceinline__ void build_key(const SqDev &sq, const RankOut &ro, do
             case KF_COMP_DESC: v = ~f64_order_key(cmp); break;
             default: v = f64_order_key(cmp); break;
         }
-        key |= (u128)v << f.shift;
+        key |= (u128)v << shift;
     }
     hi = (u64)(key >> 64); lo = (u64)key;
 }
 
-__device__ __forceinline__ void or_key_bits(const SqDev &sq, u64 a, u64 b, u64 na, u64 nb) {
+__device__ __forceinline__ void or_key_bits(u64 *key_andor, u64 a, u64 b, u64 na, u64 nb) {
     // bits that differ between keys: OR of keys and OR of complements
     a = wave_or64(a); b = wave_or64(b); na = wave_or64(na); nb = wave_or64(nb);
     if ((threadIdx.x & 63) == 0 && (a | b | na | nb)) {
-        atomicOr((u64 *)&sq.key_andor[0], na); atomicOr((u64 *)&sq.key_andor[1], nb);
-        atomicOr((u64 *)&sq.key_andor[2], a);  atomicOr((u64 *)&sq.key_andor[3], b);
+        atomicOr((u64 *)&key_andor[0], na); atomicOr((u64 *)&key_andor[1], nb);
+        atomicOr((u64 *)&key_andor[2], a);  atomicOr((u64 *)&key_andor[3], b);
     }
 }
 
@@ -401,7 +437,8 @@ __device__ __forceinline__ void or_key_bits(const SqDev &sq, u64 a, u64 b, u64 n
 extern __shared__ uint2 dyn_tab[];
 __global__ __launch_bounds__(MG_BLOCK) void k_rank_tile(const SqDev *sqs, const uint32_t *blob,
                                                         const uint2 *tile_list, const uint32_t *tile_count) {
-    __shared__ uint32_t s_e0[MG_BLOCK], s_len[MG_BLOCK], s_cnt[MG_BLOCK];
+    __shared__ uint32_t s_doc[MG_BLOCK], s_pbase[MG_BLOCK], s_cnt[MG_BLOCK], s_np[MG_BLOCK];
+    __shared__ double s_val[MG_BLOCK];
     __shared__ uint2 s_match[MG_BLOCK * MG_MCAP];
     __shared__ uint32_t s_pairs[MG_BLOCK * MG_PCAP];
     const uint32_t ntiles = *tile_count;
@@ -409,61 +446,126 @@ __global__ __launch_bounds__(MG_BLOCK) void k_rank_tile(const SqDev *sqs, const 
     const uint32_t grp = tid >> 4, gl = tid & 15;
     for (uint32_t w = blockIdx.x; w < ntiles; w += gridDim.x) {
         DBG_T(t0);
-        const uint2 item = tile_list[w];
-        const SqDev &sq = sqs[item.x];
-        const int do_rank = sq.do_rank;
+        // the work item is the same for every lane: say so, so that the descriptor is read with scalar loads
+        const uint2 item_v = tile_list[w];
+        const uint2 item = make_uint2(__builtin_amdgcn_readfirstlane(item_v.x), __builtin_amdgcn_readfirstlane(item_v.y));
+        // Every field of the descriptor that this tile needs, read in ONE burst of independent loads
+        // (the compiler cannot prove the descriptor constant across the stores below and would
+        // otherwise re-read each field, serially, at its point of use).
+        const SqDev *sp = &sqs[item.x];
+        const int do_rank = sp->do_rank;
+        const uint32_t *p_num_hits = sp->num_hits;
+        const uint32_t *p_hits = sp->hits;
+        const uint32_t hmask = sp->hash_mask, hash_off = sp->hash_off;
+        const int rb = sp->rank_by;
+        const uint32_t rec_nnum = sp->sh.rec_nnum, rec_stride = sp->sh.rec_stride;
+        const uint4 *rec = (const uint4 *)sp->sh.rec;
+        const uint2 *dw = sp->sh.dw;
+        const uint32_t *pp = sp->sh.pp;
+        const int nw = sp->num_words, nt = sp->num_terms;
+        const uint32_t exact_present = sp->exact_present;
+        u64 *p_key_hi = (u64 *)sp->key_hi, *p_key_lo = (u64 *)sp->key_lo, *p_key_andor = (u64 *)sp->key_andor;
+        uint32_t *p_ovf_cnt = sp->ovf_cnt, *p_ovf_list = sp->ovf_list;
+        const KeyLayout kl = load_key_layout(sp);
+        const double *col = sp->sh.num_col[rb >= 0 ? rb : 0];
         if (do_rank < 0) continue;                   // no hits requested: nobody reads the keys
-        const uint32_t M = *sq.num_hits;
-        const uint32_t hmask = sq.hash_mask;
-        const uint2 *gtab = (const uint2 *)(blob + sq.hash_off);
-        const uint2 *htab = gtab;
+        const uint32_t M = *p_num_hits;
+        const uint2 *gtab = (const uint2 *)(blob + hash_off);
         const uint32_t t = item.y * MG_BLOCK + tid;
         const bool valid = t < M;
-        const uint32_t docid = valid ? sq.hits[t] : 0;
-        uint32_t pbase = 0;
-        if (do_rank) {
-            if (hmask < MG_LDS_HASH) {
+        const uint32_t docid = valid ? p_hits[t] : 0xFFFFFFFFu;
+        const bool val_in_rec = rb >= 0 && (uint32_t)rb < rec_nnum;
+        if (do_rank || val_in_rec) {
+            if (do_rank && hmask < MG_LDS_HASH)
                 for (uint32_t i = tid; i <= hmask; i += MG_BLOCK) dyn_tab[i] = gtab[i];
-                htab = dyn_tab;
-            }
-            uint32_t e0 = 0, len = 0;
-            if (valid) { e0 = sq.sh.dw_off[docid]; len = sq.sh.dw_off[docid + 1] - e0; pbase = sq.sh.pp_off[docid]; }
-            s_e0[tid] = e0; s_len[tid] = len; s_cnt[tid] = 0;
+            s_doc[tid] = docid; s_cnt[tid] = 0; s_np[tid] = 0;
             __syncthreads();
             DBG_T(t1); DBG_ADD(0, t0, t1);
-            const uint2 *dw = sq.sh.dw;
-            // group g owns documents 16g .. 16g+15 of the tile; lane gl reads entry gl of each.  The 16
-            // loads are issued back to back (one memory latency for the whole group step, not 16).
-            uint2 wi[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const uint32_t d = grp * 16 + k;
-                wi[k] = (gl < s_len[d]) ? dw[s_e0[d] + gl] : make_uint2(0u, 0u);
-            }
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const uint32_t d = grp * 16 + k;
+            const uint32_t S16 = rec_stride >> 4;                  // uint4 per record
+            // group g owns documents 16g .. 16g+15 of the tile and reads each record as ONE coalesced
+            // load of 16 bytes per lane (256 B); eight records are in flight per lane at a time.
+            // two explicit probe paths: through a runtime-selected pointer the compiler would emit
+            // flat loads (LDS or global decided per access) and wait on each one
+            const bool tab_in_lds = do_rank && hmask < MG_LDS_HASH;
+            auto take = [&](uint32_t d, uint32_t wid, uint32_t info) {
                 uint32_t val;
-                if (wi[k].x && probe_wid(htab, hmask, wi[k].x, val)) {
+                const bool found = tab_in_lds ? probe_wid(dyn_tab, hmask, wid, val) : probe_wid(gtab, hmask, wid, val);
+                if (found) {
                     const uint32_t r = atomicAdd(&s_cnt[d], 1u);
-                    if (r < MG_MCAP) s_match[d * MG_MCAP + r] = make_uint2(val, wi[k].y);
+                    if (r < MG_MCAP) s_match[d * MG_MCAP + r] = make_uint2(val, info);
                 }
-            }
-            // documents with more than 16 distinct words: the rest of their runs
-            for (int k = 0; k < 16; k++) {
-                const uint32_t d = grp * 16 + k;
-                const uint32_t len_d = s_len[d], e0_d = s_e0[d];
-                for (uint32_t j = 16 + gl; j < len_d; j += 16) {
-                    const uint2 w2 = dw[e0_d + j];
-                    uint32_t val;
-                    if (probe_wid(htab, hmask, w2.x, val)) {
-                        const uint32_t r = atomicAdd(&s_cnt[d], 1u);
-                        if (r < MG_MCAP) s_match[d * MG_MCAP + r] = make_uint2(val, w2.y);
+            };
+            for (int half = 0; half < 2; half++) {
+                uint4 v[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const uint32_t doc = s_doc[grp * 16 + half * 8 + k];
+                    v[k] = (doc != 0xFFFFFFFFu && gl < S16) ? rec[(size_t)doc * S16 + gl] : make_uint4(0u, 0u, 0u, 0u);
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const uint32_t d = grp * 16 + half * 8 + k;
+                    const uint32_t h0 = __shfl(v[k].x, 0, 16), h1 = __shfl(v[k].y, 0, 16);
+                    const uint32_t h2 = __shfl(v[k].z, 0, 16), h3 = __shfl(v[k].w, 0, 16);
+                    const uint32_t nwords = h0 & 0xFFFFu, nin = h0 >> 16, ws = h3 >> 16;
+                    if (gl == 0) s_pbase[d] = h1;
+                    if (val_in_rec && gl == (uint32_t)(1 + (rb >> 1))) {
+                        const u64 bits = (rb & 1) ? (((u64)v[k].w << 32) | v[k].z) : (((u64)v[k].y << 32) | v[k].x);
+                        s_val[d] = __longlong_as_double((long long)bits);
+                    }
+                    if (!do_rank) continue;
+                    const uint32_t s0 = 2 * gl;
+                    if (s0 >= ws && s0 < ws + nin) take(d, v[k].x, v[k].y);
+                    if (s0 + 1 >= ws && s0 + 1 < ws + nin) take(d, v[k].z, v[k].w);
+                    // records longer than 256 B, then the words that did not fit the record at all
+                    if (nin + ws > 32) {
+                        const uint32_t doc = s_doc[d];
+                        for (uint32_t c = 16 + gl; c < S16; c += 16) {
+                            const uint4 x = rec[(size_t)doc * S16 + c];
+                            if (2 * c >= ws && 2 * c < ws + nin) take(d, x.x, x.y);
+                            if (2 * c + 1 >= ws && 2 * c + 1 < ws + nin) take(d, x.z, x.w);
+                        }
+                    }
+                    for (uint32_t j = nin + gl; j < nwords; j += 16) {
+                        const uint2 w2 = dw[h2 + (j - nin)];
+                        take(d, w2.x, w2.y);
                     }
                 }
             }
             __syncthreads();
             DBG_T(t2); DBG_ADD(1, t1, t2);
+            // Phase 1b, one lane per match record: fetch the word's positions (the only dependent
+            // global read of the ranking, issued for all records of the tile at once), turn them into
+            // (slot, position) pairs in the document's LDS slice and leave {val, first position}
+            // behind, so that phase 2 never leaves LDS.
+            if (do_rank) {
+                for (uint32_t sl = tid; sl < MG_BLOCK * MG_MCAP; sl += MG_BLOCK) {
+                    const uint32_t d = sl / MG_MCAP, r = sl % MG_MCAP;
+                    if (r >= s_cnt[d]) continue;
+                    const uint2 m = s_match[sl];
+                    if ((m.x & 0xFF) == 0xFF) continue;                 // exact-only entry: no positions needed
+                    const uint32_t info = m.y;
+                    const bool inl = info & 1u;
+                    const uint32_t cnt = inl ? 1u : ((info >> 1) & 0xFFu);
+                    const uint32_t *pd = pp + s_pbase[d] + (info >> 9);
+                    const uint32_t first = inl ? info_first_inline(info) : pd[0];
+                    s_match[sl].y = first;
+                    if (nw == 1) continue;
+                    int slot_a, slot_b; bool keep_a;
+                    rank_slots(nw, nt, (m.x >> 8) & 0xFF, slot_a, slot_b, keep_a);
+                    const uint32_t per = (keep_a ? 1u : 0u) + (slot_b >= 0 ? 1u : 0u);
+                    if (!per) continue;
+                    const uint32_t at = atomicAdd(&s_np[d], per * cnt);
+                    if (at + per * cnt > MG_PCAP) continue;             // phase 2 sees s_np > MG_PCAP: overflow path
+                    uint32_t o = at;
+                    for (uint32_t j = 0; j < cnt; j++) {
+                        const uint32_t p = (j == 0) ? first : pd[j];
+                        if (keep_a) s_pairs[(o++) * MG_BLOCK + d] = ((uint32_t)slot_a << 24) | p;
+                        if (slot_b >= 0) s_pairs[(o++) * MG_BLOCK + d] = ((uint32_t)slot_b << 24) | p;
+                    }
+                }
+                __syncthreads();
+            }
         }
         DBG_T(t3);
         u64 a = 0, b = 0, na = 0, nb = 0;
@@ -476,23 +578,23 @@ __global__ __launch_bounds__(MG_BLOCK) void k_rank_tile(const SqDev *sqs, const 
                 else {
                     RankState st; rank_init(st);
                     LdsPairs ps = {&s_pairs[tid], MG_PCAP};
-                    const int nw = sq.num_words, nt = sq.num_terms;
                     for (uint32_t r = 0; r < cnt; r++) {
                         const uint2 m = s_match[tid * MG_MCAP + r];
-                        rank_consume(st, nw, nt, m.x, m.y, sq.sh.pp + pbase, ps);
+                        rank_reduce(st, nw, nt, m.x, m.y);
                     }
-                    if (st.ovf) ok = false; else rank_finish(st, nw, sq.exact_present, ps, ro);
+                    st.np = (int)s_np[tid];
+                    if (st.np > MG_PCAP) ok = false; else rank_finish(st, nw, exact_present, ps, ro);
                 }
-                if (!ok) sq.ovf_list[atomicAdd(sq.ovf_cnt, 1u)] = t;
+                if (!ok) p_ovf_list[atomicAdd(p_ovf_cnt, 1u)] = t;
             }
             if (ok) {
                 u64 hi, lo;
-                build_key(sq, ro, (sq.rank_by >= 0) ? sq.sh.num_col[sq.rank_by][docid] : 0.0, hi, lo);
-                sq.key_hi[t] = hi; sq.key_lo[t] = lo;
+                build_key(kl, ro, val_in_rec ? s_val[tid] : (rb >= 0 ? col[docid] : 0.0), hi, lo);
+                p_key_hi[t] = hi; p_key_lo[t] = lo;
                 a = hi; b = lo; na = ~hi; nb = ~lo;
             }
         }
-        or_key_bits(sq, a, b, na, nb);
+        or_key_bits(p_key_andor, a, b, na, nb);
         __syncthreads();                             // LDS is reused by the next work item
         DBG_T(t4); DBG_ADD(2, t3, t4); DBG_CNT(3);
     }
@@ -509,6 +611,7 @@ __global__ __launch_bounds__(MG_BLOCK) void k_rank_overflow(const SqDev *sqs, co
     const uint2 *htab = (const uint2 *)(blob + sq.hash_off);
     const uint32_t hmask = sq.hash_mask;
     const int nw = sq.num_words, nt = sq.num_terms;
+    const KeyLayout kl = load_key_layout(&sq);
     u64 a = 0, b = 0, na = 0, nb = 0;
     for (uint32_t base = blockIdx.x * MG_BLOCK; base < M; base += gridDim.x * MG_BLOCK) {
         const uint32_t t = base + threadIdx.x;
@@ -532,11 +635,11 @@ __global__ __launch_bounds__(MG_BLOCK) void k_rank_overflow(const SqDev *sqs, co
         RankOut ro = {0, 0, 0, 0, 0};
         rank_finish(st, nw, sq.exact_present, ps, ro);
         u64 hi, lo;
-        build_key(sq, ro, (sq.rank_by >= 0) ? sq.sh.num_col[sq.rank_by][docid] : 0.0, hi, lo);
+        build_key(kl, ro, (sq.rank_by >= 0) ? sq.sh.num_col[sq.rank_by][docid] : 0.0, hi, lo);
         sq.key_hi[hidx] = hi; sq.key_lo[hidx] = lo;
         a |= hi; b |= lo; na |= ~hi; nb |= ~lo;
     }
-    or_key_bits(sq, a, b, na, nb);
+    or_key_bits((u64 *)sq.key_andor, a, b, na, nb);
 }
 
 // appends `v` to list[*n] for every lane whose `pred` is set, with one atomic per wave
@@ -559,7 +662,9 @@ __global__ __launch_bounds__(MG_BLOCK) void k_docproc(const SqDev *sqs, const ui
     __shared__ AggPart red[MG_BLOCK / 64];
     const uint32_t ntiles = *tile_count;
     for (uint32_t w = blockIdx.x; w < ntiles; w += gridDim.x) {
-        const uint2 item = tile_list[w];
+        // the work item is the same for every lane: say so, so that the descriptor is read with scalar loads
+        const uint2 item_v = tile_list[w];
+        const uint2 item = make_uint2(__builtin_amdgcn_readfirstlane(item_v.x), __builtin_amdgcn_readfirstlane(item_v.y));
         const SqDev &sq = sqs[item.x];
         // The hit list is cut into nproc_blocks interleaved slices (fixed by the shard size so that
         // the f64 reduction tree never depends on the batch); work item (sq, vb) is slice vb, and
@@ -569,6 +674,9 @@ __global__ __launch_bounds__(MG_BLOCK) void k_docproc(const SqDev *sqs, const ui
         const uint32_t M = *sq.num_hits;
         const uint32_t stride = nvb * MG_BLOCK;
 
+        const uint32_t S4 = sq.sh.rec_stride >> 2;
+        const uint32_t *rec = sq.sh.rec;
+        const uint32_t nnum_in = sq.sh.rec_nnum;
         for (int f = 0; f < sq.sh.num_facets; f++) {
             if (!((sq.hist_mask >> f) & 1u)) continue;
             const uint32_t nord = sq.sh.fa_nord[f];
@@ -583,9 +691,17 @@ __global__ __launch_bounds__(MG_BLOCK) void k_docproc(const SqDev *sqs, const ui
             }
             for (uint32_t i = vb * MG_BLOCK + threadIdx.x; i < M; i += stride) {
                 const uint32_t d = sq.hits[i];
-                const uint32_t a = off[d], b = off[d + 1];
-                for (uint32_t j = a; j < b; j++) {
-                    const uint32_t o = ord[j];
+                // the document's ordinals for field f: from its record when they fit there (the line
+                // the rank stage just read), else from the per-field CSR
+                const uint32_t *r = rec + (size_t)d * S4;
+                const uint32_t *vals; uint32_t cnt;
+                if ((r[3] >> 8) & 1u) {
+                    const uint32_t *fp = r + 4 + 2 * nnum_in;
+                    for (int g = 0; g < f; g++) fp += 1 + fp[0];
+                    cnt = fp[0]; vals = fp + 1;
+                } else { const uint32_t a0 = off[d]; cnt = off[d + 1] - a0; vals = ord + a0; }
+                for (uint32_t j = 0; j < cnt; j++) {
+                    const uint32_t o = vals[j];
                     if (use_lds) atomicAdd(&hist[o], 1u);
                     else wave_append(atomicAdd(&gh[o], 1u) == 0, o, tl, tn);          // first touch: remember the bin
                 }
@@ -603,11 +719,14 @@ __global__ __launch_bounds__(MG_BLOCK) void k_docproc(const SqDev *sqs, const ui
 
         for (int a = 0; a < sq.num_aggs; a++) {
             if (sq.agg_type[a] == MGPU_A_CARDINALITY) continue;
-            const double *col = sq.sh.num_col[sq.agg_field[a]];
+            const uint32_t af = (uint32_t)sq.agg_field[a];
+            const double *col = sq.sh.num_col[af];
+            const bool in_rec = af < nnum_in;
             double sum = 0.0, mn = 1.7976931348623157e308, mx = -1.7976931348623157e308;
             unsigned long long cnt = 0;
             for (uint32_t i = vb * MG_BLOCK + threadIdx.x; i < M; i += stride) {
-                const double v = col[sq.hits[i]];
+                const uint32_t d = sq.hits[i];
+                const double v = in_rec ? *(const double *)(rec + (size_t)d * S4 + 4 + 2 * af) : col[d];
                 if (v != -1.7976931348623157e308) {          // get_num_value's "no value" marker, metric-aggs.c:106,149
                     sum += v; mn = v < mn ? v : mn; mx = v > mx ? v : mx; cnt++;
                 }
@@ -701,20 +820,44 @@ __device__ __forceinline__ bool mask_bit(u64 mhi, u64 mlo, uint32_t midx, uint32
 // Called by one thread; the table lives in LDS so that no kernel here needs private arrays.
 __device__ __forceinline__ int digit_bits(u64 mhi, u64 mlo, uint32_t midx, uint32_t from, uint32_t *pos, uint32_t *next) {
     int n = 0;
-    uint32_t b = from;
-    for (; b < 160 && n < MG_SEL_DIGIT; b++) {
-        if (!mask_bit(mhi, mlo, midx, b)) continue;
-        pos[n++] = b < 64 ? (63 - b) : b < 128 ? ((1u << 8) | (127 - b)) : ((2u << 8) | (159 - b));
+    uint32_t b = from;                       // bit b of the 160-bit (hi, lo, idx) string, MSB first
+    while (n < MG_SEL_DIGIT && b < 160) {
+        if (b < 128) {
+            const uint32_t base = b < 64 ? 0u : 64u, o = b - base;
+            const u64 m = (b < 64 ? mhi : mlo) & (o == 0 ? ~0ull : ((1ull << (64 - o)) - 1ull));
+            if (!m) { b = base + 64; continue; }
+            b = base + (uint32_t)__clzll((long long)m);
+            pos[n++] = base == 0 ? (63 - b) : ((1u << 8) | (127 - b));
+            b++;
+        } else {
+            const uint32_t o = b - 128;
+            const uint32_t m = midx & (o == 0 ? ~0u : ((1u << (32 - o)) - 1u));
+            if (!m) { b = 160; break; }
+            b = 128 + (uint32_t)__clz((int)m);
+            pos[n++] = (2u << 8) | (159 - b);
+            b++;
+        }
     }
     *next = b;
     return n;
 }
-__device__ __forceinline__ uint32_t digit_of(u64 hi, u64 lo, uint32_t idx, const uint32_t *pos, int n) {
+// the digit's bit positions held in registers (loaded once per pass from the LDS table)
+struct DigitPos { uint32_t e[MG_SEL_DIGIT]; int n; };
+__device__ __forceinline__ DigitPos load_digit_pos(const uint32_t *pos, int n) {
+    DigitPos d; d.n = n;
+#pragma unroll
+    for (int j = 0; j < MG_SEL_DIGIT; j++) d.e[j] = pos[j];
+    return d;
+}
+__device__ __forceinline__ uint32_t digit_of(u64 hi, u64 lo, uint32_t idx, const DigitPos &p) {
     uint32_t d = 0;
-    for (int j = 0; j < n; j++) {
-        const uint32_t e = pos[j], w = e >> 8, sh = e & 0xFF;
-        const u64 v = w == 0 ? hi : w == 1 ? lo : (u64)idx;
-        d = (d << 1) | (uint32_t)((v >> sh) & 1u);
+#pragma unroll
+    for (int j = 0; j < MG_SEL_DIGIT; j++) {
+        if (j < p.n) {
+            const uint32_t e = p.e[j], w = e >> 8, sh = e & 0xFF;
+            const u64 v = w == 0 ? hi : w == 1 ? lo : (u64)idx;
+            d = (d << 1) | (uint32_t)((v >> sh) & 1u);
+        }
     }
     return d;
 }
@@ -745,10 +888,11 @@ struct SelOut { u64 *out_hi, *out_lo; uint32_t *out_pl; const uint32_t *payload;
 // emit the first k.  s_cnt: two LDS words.
 template <int CAP>
 __device__ __forceinline__ void sel_final(const SelJob &job, const SelOut &out, uint32_t pass, uint32_t nin, uint32_t nwin,
-                                          uint32_t dstar, const uint32_t *rin, const uint32_t *pprev, int nprev,
+                                          uint32_t dstar, const uint32_t *rin, const uint32_t *pprev_lds, int nprev,
                                           u64 *s_hi, u64 *s_lo, uint32_t *s_ix, uint32_t *s_cnt) {
     if (threadIdx.x == 0) { s_cnt[0] = 0; s_cnt[1] = 0; }
     __syncthreads();
+    const DigitPos pprev = load_digit_pos(pprev_lds, nprev);
     for (uint32_t i = threadIdx.x; i < nwin; i += MG_BLOCK) {
         const uint32_t idx = job.out_idx[i];
         const uint32_t p = atomicAdd(&s_cnt[0], 1u);
@@ -766,7 +910,7 @@ __device__ __forceinline__ void sel_final(const SelJob &job, const SelOut &out, 
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             bool take = idxs[u] != 0xFFFFFFFFu;
-            if (take && pass > 0) take = digit_of(his[u], los[u], idxs[u], pprev, nprev) <= dstar;
+            if (take && pass > 0) take = digit_of(his[u], los[u], idxs[u], pprev) <= dstar;
             if (take) {
                 const uint32_t p = atomicAdd(&s_cnt[0], 1u);
                 if (p < CAP) { s_hi[p] = his[u]; s_lo[p] = los[u]; s_ix[p] = idxs[u]; }
@@ -810,13 +954,14 @@ __device__ __forceinline__ void sel_final(const SelJob &job, const SelOut &out, 
 // workgroup (the common case: a shard's hits for one query) never come back to the host: that
 // workgroup keeps iterating passes in LDS until the answer fits the final sort, and when that
 // sort is small it does it on the spot (SEL_DONE = 2): no further launch touches the job.
-__global__ __launch_bounds__(MG_BLOCK) void k_select_pass(const SelJob *jobs, const SelOut *outs) {
+__global__ __launch_bounds__(MG_BLOCK) void k_select_pass(const SelJob *jobs, const SelOut *outs, int solo_only) {
     const SelJob job = jobs[blockIdx.y];
     uint32_t *ctl = job.ctl;
     const uint32_t M = *job.m_ptr;
     __shared__ u64 s_fhi[SEL_SMALL_CAP], s_flo[SEL_SMALL_CAP];
     __shared__ uint32_t s_fix[SEL_SMALL_CAP], s_fcnt[2];
     DBG_T(ts0);
+    DbgScope dbg_scope(13); dbg_scope.tag = M;
     // until a final sort has run the host must see "not finished"
     if (blockIdx.x == 0 && threadIdx.x == 0 &&
         __hip_atomic_load(&ctl[SEL_DONE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 2u) *job.out_n = 0xFFFFFFFFu;
@@ -845,6 +990,9 @@ __global__ __launch_bounds__(MG_BLOCK) void k_select_pass(const SelJob *jobs, co
             if (small) sel_final<SEL_SMALL_CAP>(job, outs[blockIdx.y], 0, M, 0, 0, nullptr, s_pcur, 0, s_fhi, s_flo, s_fix, s_fcnt);
             return;
         }
+        // first launch of a batch: one workgroup per job, lists beyond a lone workgroup's reach are
+        // left for the continuation rounds (which bring a wider grid)
+        if (solo_only && nin > SEL_SOLO_CHUNKS * SEL_CHUNK) return;
         const uint32_t nb = sel_nblocks(nin, gridDim.x);
         if (!continuing && vbid >= nb) return;
         const bool solo = nb == 1;
@@ -866,6 +1014,7 @@ __global__ __launch_bounds__(MG_BLOCK) void k_select_pass(const SelJob *jobs, co
         __syncthreads();
         const int nprev = (int)s_nprev, ncur = (int)s_ncur;
         const uint32_t next_bitpos = s_nextbit;
+        const DigitPos dprev = load_digit_pos(s_pprev, nprev), dcur = load_digit_pos(s_pcur, ncur);
         DBG_T(ts1); DBG_ADD(4, ts0, ts1);
 
         const uint32_t nch = (nin + SEL_CHUNK - 1) / SEL_CHUNK;
@@ -887,7 +1036,7 @@ __global__ __launch_bounds__(MG_BLOCK) void k_select_pass(const SelJob *jobs, co
                 const uint32_t idx = idxs[it]; const u64 hi = his[it], lo = los[it];
                 bool keep = idx != 0xFFFFFFFFu, winner = false;
                 if (keep && pass > 0) {
-                    const uint32_t dp = digit_of(hi, lo, idx, s_pprev, nprev);
+                    const uint32_t dp = digit_of(hi, lo, idx, dprev);
                     if (dp < dstar) { winner = true; keep = false; }
                     else if (dp > dstar) keep = false;
                 }
@@ -909,7 +1058,7 @@ __global__ __launch_bounds__(MG_BLOCK) void k_select_pass(const SelJob *jobs, co
                     if (keep) rout[bk + (uint32_t)__popcll(mk & below)] = idx;
                     if (winner) win[bw + (uint32_t)__popcll(mw & below)] = idx;
                 }
-                if (keep) atomicAdd(&hist[digit_of(hi, lo, idx, s_pcur, ncur)], 1u);
+                if (keep) atomicAdd(&hist[digit_of(hi, lo, idx, dcur)], 1u);
             }
         }
         __syncthreads();
@@ -992,7 +1141,7 @@ __global__ __launch_bounds__(MG_BLOCK) void k_select_pass(const SelJob *jobs, co
             __syncthreads();
             sel_final<SEL_SMALL_CAP>(job, outs[blockIdx.y], pass + 1, nkept, nwin_total, d_fin,
                                      (pass + 1 <= 1) ? nullptr : (newbuf ? job.cand[1] : job.cand[0]), s_pcur, ncur, s_fhi, s_flo, s_fix, s_fcnt);
-            DBG_T(ts4); DBG_ADD(7, ts3, ts4); DBG_CNT(8);
+            DBG_T(ts4); DBG_ADD(7, ts3, ts4); DBG_CNT(8); DBG_MAX(9, ts0, ts4, M); DBG_MAX(10, ts3, ts4, M); DBG_MAX(11, ts1, ts2, M); DBG_MAX(12, ts0, ts1, M);
             return;
         }
         if (!go_on) return;
@@ -1046,7 +1195,30 @@ __global__ __launch_bounds__(MG_BLOCK) void k_row_op(const u64 *a, const u64 *b,
 }
 
 // ------------------------------------------------------------------ launch wrappers (called from mgpu_api.hip)
+__global__ void k_nop(int *p) { if (p) *p = 0; }
+__global__ void k_clock_cal(unsigned long long *out) {
+    const unsigned long long w0 = wall_clock64(), c0 = clock64();
+    unsigned long long w1 = w0;
+    while (w1 - w0 < 1000) w1 = wall_clock64();          // bounded: the wall clock always advances
+    out[0] = w1 - w0; out[1] = clock64() - c0;
+}
 extern "C" {
+// diagnostic: ticks of wall_clock64 and of the shader clock over the same interval, plus the host's view in ns
+int mgk_debug_clock_cal(unsigned long long *out3) {
+    unsigned long long *d = nullptr;
+    if (hipMalloc(&d, 16) != hipSuccess) return -1;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k_clock_cal, dim3(1), dim3(1), 0, 0, d);      // warm
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(k_clock_cal, dim3(1), dim3(1), 0, 0, d);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    hipMemcpy(out3, d, 16, hipMemcpyDeviceToHost);
+    out3[2] = (unsigned long long)(ms * 1e6);
+    hipFree(d); hipEventDestroy(e0); hipEventDestroy(e1);
+    return 0;
+}
 // phase clocks: enable, and read + reset the 16 accumulators (100 MHz wall_clock64 ticks)
 int mgk_debug_phases(int on, unsigned long long *out16) {
     unsigned long long z[16] = {0};
@@ -1104,15 +1276,18 @@ void mgk_card(hipStream_t st, const void *jobs, uint32_t njobs, uint32_t max_n) 
 // 1: also the stand-alone final sorts, for the continuation rounds of larger jobs.
 void mgk_select(hipStream_t st, const SelJob *jobs, const void *outs, uint32_t njobs, uint32_t max_m, int passes, int finals) {
     if (!njobs) return;
-    // enough workgroups to fill the chip, never one per chunk of the largest possible list:
-    // workgroups stride over chunks, and most jobs end up in a single workgroup anyway
+    if (!finals) {
+        // first go: exactly one workgroup per job, no idle ones
+        hipLaunchKernelGGL(k_select_pass, dim3(1, njobs), dim3(MG_BLOCK), 0, st, jobs, (const SelOut *)outs, 1);
+        if (getenv("MGPU_NOP")) hipLaunchKernelGGL(k_nop, dim3(1), dim3(64), 0, st, (int *)nullptr);
+        return;
+    }
+    // continuation: enough workgroups per job to fill the chip, striding over chunks
     uint32_t gx = (max_m + SEL_CHUNK - 1) / SEL_CHUNK;
-    uint32_t cap = 4096 / njobs; if (cap < 1) cap = 1;
-    if (cap < 4) cap = 4;
+    uint32_t cap = 4096 / njobs; if (cap < 4) cap = 4;
     if (gx <= SEL_SOLO_CHUNKS) gx = 1; else if (gx > cap) gx = cap;
     for (int p = 0; p < passes; p++)
-        hipLaunchKernelGGL(k_select_pass, dim3(gx, njobs), dim3(MG_BLOCK), 0, st, jobs, (const SelOut *)outs);
-    if (!finals) return;
+        hipLaunchKernelGGL(k_select_pass, dim3(gx, njobs), dim3(MG_BLOCK), 0, st, jobs, (const SelOut *)outs, 0);
     hipLaunchKernelGGL((k_select_final<SEL_SMALL_CAP, 0>), dim3(njobs), dim3(MG_BLOCK), 0, st, jobs, (const SelOut *)outs);
     hipLaunchKernelGGL((k_select_final<SEL_BIG_CAP, SEL_SMALL_CAP + 1>), dim3(njobs), dim3(MG_BLOCK), 0, st, jobs, (const SelOut *)outs);
 }

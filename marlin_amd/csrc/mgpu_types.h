@@ -32,6 +32,12 @@ struct ShardDev {
     const uint2    *dw;              // {wid, info}
     const uint32_t *pp_off;          // [N + 1] decoded position pool ((priority << 16) + position)
     const uint32_t *pp;
+    // doc-major records: one aligned record of rec_stride bytes per docid:
+    //   u32 nwords | nin << 16 ; u32 pbase ; u32 ovf (= dw_off[doc] + nin) ; u32 nnum_in | facets_in << 8 | ws << 16
+    //   f64 x nnum_in ; [facet section: per field u32 count + ordinals] ; from 8-byte slot ws: nin x {wid, info}
+    const uint32_t *rec;
+    uint32_t rec_stride;             // bytes: 128, 256, 384 or 512
+    uint32_t rec_nnum;               // numbers held in every record (all of them when num_numbers <= 4, else 0)
     // facets
     int32_t  num_facets, num_numbers;
     const uint32_t *fa_off[MGPU_MAX_FIELDS];    // [N + 1]

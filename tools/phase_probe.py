@@ -21,12 +21,23 @@ pool = [ix.query(j) for j in bench.make_queries(lib, 64)]
 prep = eng.prepare(pool[:32])
 for _ in range(3):
     eng.free_raw(eng.execute_prepared(prep))
+eng.set_profiling(True)
+eng.free_raw(eng.execute_prepared(prep))
+print("stage ms (no phase clocks):", {k: round(x["ms"], 4) for k, x in eng.timing()["stages"].items()})
 gpu.mgk_debug_phases(1, None)
-for _ in range(5):
+for _ in range(1):
     eng.free_raw(eng.execute_prepared(prep))
+print("stage ms (with phase clocks):", {k: round(x["ms"], 4) for k, x in eng.timing()["stages"].items()})
 out = (C.c_ulonglong * 16)()
 gpu.mgk_debug_phases(0, out)
 v = list(out)
 tiles = max(1, v[3]); jobs = max(1, v[8])
-print("rank tiles/launch", tiles / 5, "per-tile us: setup %.2f phase1 %.2f phase2 %.2f" % (v[0] / tiles / 100, v[1] / tiles / 100, v[2] / tiles / 100))
-print("select fused jobs/launch", jobs / 5, "us per WG (all WGs incl. idle contribute to setup): setup %.2f chunks %.2f decide %.2f final %.2f" % (v[4] / jobs / 100, v[5] / jobs / 100, v[6] / jobs / 100, v[7] / jobs / 100))
+print("rank tiles/launch", tiles / 1, "per-tile us: setup %.2f phase1 %.2f phase2 %.2f" % (v[0] / tiles / 100, v[1] / tiles / 100, v[2] / tiles / 100))
+print("select fused jobs/launch", jobs / 1, "us per WG (all WGs incl. idle contribute to setup): setup %.2f chunks %.2f decide %.2f final %.2f" % (v[4] / jobs / 100, v[5] / jobs / 100, v[6] / jobs / 100, v[7] / jobs / 100))
+for slot, name in ((13, "ANY exit WG"), (9, "whole WG"), (10, "final"), (11, "chunks"), (12, "setup")):
+    print("select max %s: %.1f us at M=%d" % (name, (v[slot] >> 32) / 100, v[slot] & 0xFFFFFFFF))
+cal = (C.c_ulonglong * 3)()
+gpu.mgk_debug_clock_cal.argtypes = [C.POINTER(C.c_ulonglong)]
+gpu.mgk_debug_clock_cal(cal)
+print("clock cal: wall ticks %d, shader cycles %d, event ns %d" % (cal[0], cal[1], cal[2]))
+print("select kernel span (first WG start -> last WG end): %.1f us" % ((v[15] - ((~v[14]) & 0xFFFFFFFFFFFFFFFF)) / 100))
