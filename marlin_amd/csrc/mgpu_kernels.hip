@@ -954,8 +954,8 @@ __device__ __forceinline__ void sel_final(const SelJob &job, const SelOut &out, 
 // workgroup (the common case: a shard's hits for one query) never come back to the host: that
 // workgroup keeps iterating passes in LDS until the answer fits the final sort, and when that
 // sort is small it does it on the spot (SEL_DONE = 2): no further launch touches the job.
-__global__ __launch_bounds__(MG_BLOCK) void k_select_pass(const SelJob *jobs, const SelOut *outs, int solo_only) {
-    const SelJob job = jobs[blockIdx.y];
+__device__ __forceinline__ void select_job(const SelJob &job, const SelOut &sel_out, int solo_only, uint32_t job_index,
+                                           uint32_t *todo_list, uint32_t *todo_count) {
     uint32_t *ctl = job.ctl;
     const uint32_t M = *job.m_ptr;
     __shared__ u64 s_fhi[SEL_SMALL_CAP], s_flo[SEL_SMALL_CAP];
@@ -986,13 +986,19 @@ __global__ __launch_bounds__(MG_BLOCK) void k_select_pass(const SelJob *jobs, co
         if (pass == 0 && (M <= SEL_SMALL_CAP || job.k >= M)) {
             if (blockIdx.x != 0) return;
             const bool small = M <= SEL_SMALL_CAP;
-            if (threadIdx.x == 0) { ctl[SEL_NIN] = M; ctl[SEL_KREM] = job.k; ctl[SEL_NFIN] = M; ctl[SEL_DONE] = small ? 2u : 1u; }
-            if (small) sel_final<SEL_SMALL_CAP>(job, outs[blockIdx.y], 0, M, 0, 0, nullptr, s_pcur, 0, s_fhi, s_flo, s_fix, s_fcnt);
+            if (threadIdx.x == 0) {
+                ctl[SEL_NIN] = M; ctl[SEL_KREM] = job.k; ctl[SEL_NFIN] = M; ctl[SEL_DONE] = small ? 2u : 1u;
+                if (!small && solo_only) todo_list[atomicAdd(todo_count, 1u)] = job_index;
+            }
+            if (small) sel_final<SEL_SMALL_CAP>(job, sel_out, 0, M, 0, 0, nullptr, s_pcur, 0, s_fhi, s_flo, s_fix, s_fcnt);
             return;
         }
         // first launch of a batch: one workgroup per job, lists beyond a lone workgroup's reach are
         // left for the continuation rounds (which bring a wider grid)
-        if (solo_only && nin > SEL_SOLO_CHUNKS * SEL_CHUNK) return;
+        if (solo_only && nin > SEL_SOLO_CHUNKS * SEL_CHUNK) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) todo_list[atomicAdd(todo_count, 1u)] = job_index;
+            return;
+        }
         const uint32_t nb = sel_nblocks(nin, gridDim.x);
         if (!continuing && vbid >= nb) return;
         const bool solo = nb == 1;
@@ -1139,11 +1145,12 @@ __global__ __launch_bounds__(MG_BLOCK) void k_select_pass(const SelJob *jobs, co
             // this workgroup is the only one left on the job: sort and emit right here
             __threadfence();
             __syncthreads();
-            sel_final<SEL_SMALL_CAP>(job, outs[blockIdx.y], pass + 1, nkept, nwin_total, d_fin,
+            sel_final<SEL_SMALL_CAP>(job, sel_out, pass + 1, nkept, nwin_total, d_fin,
                                      (pass + 1 <= 1) ? nullptr : (newbuf ? job.cand[1] : job.cand[0]), s_pcur, ncur, s_fhi, s_flo, s_fix, s_fcnt);
             DBG_T(ts4); DBG_ADD(7, ts3, ts4); DBG_CNT(8); DBG_MAX(9, ts0, ts4, M); DBG_MAX(10, ts3, ts4, M); DBG_MAX(11, ts1, ts2, M); DBG_MAX(12, ts0, ts1, M);
             return;
         }
+        if (done && !fused && solo_only && threadIdx.x == 0) todo_list[atomicAdd(todo_count, 1u)] = job_index;
         if (!go_on) return;
         // next pass in this launch: make this pass's list and control words visible to the whole workgroup
         __threadfence();
@@ -1151,11 +1158,35 @@ __global__ __launch_bounds__(MG_BLOCK) void k_select_pass(const SelJob *jobs, co
     }
 }
 
+// first launch of a batch: grid (1, njobs), one workgroup per job.  Jobs it cannot finish (lists
+// beyond a lone workgroup, final sets beyond the small sort) are put on the to-do list.
+__global__ __launch_bounds__(MG_BLOCK) void k_select_pass(const SelJob *jobs, const SelOut *outs, int solo_only,
+                                                          uint32_t *todo_list, uint32_t *todo_count) {
+    const SelJob job = jobs[blockIdx.y];
+    select_job(job, outs[blockIdx.y], solo_only, blockIdx.y, todo_list, todo_count);
+}
+// the wide passes over the to-do list, enqueued behind the first launch without a host round trip:
+// grid (gx, gy), workgroup (x, y) is workgroup x of jobs todo[y], todo[y + gy], ...
+__global__ __launch_bounds__(MG_BLOCK) void k_select_todo(const SelJob *jobs, const SelOut *outs,
+                                                          const uint32_t *todo_list, const uint32_t *todo_count) {
+    const uint32_t n = *todo_count;
+    for (uint32_t y = blockIdx.y; y < n; y += gridDim.y) {
+        const uint32_t ji = todo_list[y];
+        const SelJob job = jobs[ji];
+        select_job(job, outs[ji], 0, ji, nullptr, nullptr);
+        __syncthreads();
+    }
+}
+
 // final stage for the jobs the pass kernel did not finish itself (large final sets, or lists that
 // needed several workgroups): one workgroup per job.  Two sizes of the same kernel.
 template <int CAP, int LO>
-__global__ __launch_bounds__(MG_BLOCK) void k_select_final(const SelJob *jobs, const SelOut *outs) {
-    const SelJob job = jobs[blockIdx.x];
+__global__ __launch_bounds__(MG_BLOCK) void k_select_final(const SelJob *jobs, const SelOut *outs,
+                                                           const uint32_t *todo_list, const uint32_t *todo_count) {
+    // with a to-do list: one launch of min(njobs, 256) workgroups serves the listed jobs only
+    uint32_t ji = blockIdx.x;
+    if (todo_list) { if (blockIdx.x >= *todo_count) return; ji = todo_list[blockIdx.x]; }
+    const SelJob job = jobs[ji];
     const uint32_t *ctl = job.ctl;
     const uint32_t M = *job.m_ptr;
     __shared__ u64 s_hi[CAP];
@@ -1175,7 +1206,7 @@ __global__ __launch_bounds__(MG_BLOCK) void k_select_final(const SelJob *jobs, c
         s_nprev = (pass > 0) ? (uint32_t)digit_bits(mhi, mlo, midx, ctl[SEL_BPREV], s_pprev, &dummy) : 0u;
     }
     __syncthreads();
-    sel_final<CAP>(job, outs[blockIdx.x], pass, ctl[SEL_NIN], ctl[SEL_NWIN], ctl[SEL_DSTAR],
+    sel_final<CAP>(job, outs[ji], pass, ctl[SEL_NIN], ctl[SEL_NWIN], ctl[SEL_DSTAR],
                    (pass <= 1) ? nullptr : (ctl[SEL_BUF] ? job.cand[1] : job.cand[0]), s_pprev, (int)s_nprev, s_hi, s_lo, s_ix, s_cnt);
 }
 
@@ -1274,22 +1305,33 @@ void mgk_card(hipStream_t st, const void *jobs, uint32_t njobs, uint32_t max_n) 
 }
 // `finals` = 0: only the pass launches (jobs that fit one workgroup finish inside them);
 // 1: also the stand-alone final sorts, for the continuation rounds of larger jobs.
-void mgk_select(hipStream_t st, const SelJob *jobs, const void *outs, uint32_t njobs, uint32_t max_m, int passes, int finals) {
+void mgk_select(hipStream_t st, const SelJob *jobs, const void *outs, uint32_t njobs, uint32_t max_m, int passes, int finals,
+                uint32_t *todo_list, uint32_t *todo_count) {
     if (!njobs) return;
+    const SelOut *so = (const SelOut *)outs;
+    uint32_t gx = (max_m + SEL_CHUNK - 1) / SEL_CHUNK;
     if (!finals) {
-        // first go: exactly one workgroup per job, no idle ones
-        hipLaunchKernelGGL(k_select_pass, dim3(1, njobs), dim3(MG_BLOCK), 0, st, jobs, (const SelOut *)outs, 1);
-        if (getenv("MGPU_NOP")) hipLaunchKernelGGL(k_nop, dim3(1), dim3(64), 0, st, (int *)nullptr);
+        // first go: exactly one workgroup per job, no idle ones ...
+        hipLaunchKernelGGL(k_select_pass, dim3(1, njobs), dim3(MG_BLOCK), 0, st, jobs, so, 1, todo_list, todo_count);
+        if (gx <= SEL_SOLO_CHUNKS && max_m <= MG_SEL_SMALL) return;       // no job of this batch can end up on the list
+        // ... then the wide passes and stand-alone sorts for whatever landed on the to-do list (usually
+        // nothing or a handful of heavy jobs; the launches are near-free when the list is empty)
+        uint32_t wx = gx <= SEL_SOLO_CHUNKS ? 1 : (gx > 64 ? 64 : gx);
+        uint32_t wy = njobs < 32 ? njobs : 32;
+        for (int p = 0; p < passes; p++)
+            hipLaunchKernelGGL(k_select_todo, dim3(wx, wy), dim3(MG_BLOCK), 0, st, jobs, so, todo_list, todo_count);
+        uint32_t fy = njobs < 256 ? njobs : 256;
+        hipLaunchKernelGGL((k_select_final<SEL_SMALL_CAP, 0>), dim3(fy), dim3(MG_BLOCK), 0, st, jobs, so, todo_list, todo_count);
+        hipLaunchKernelGGL((k_select_final<SEL_BIG_CAP, SEL_SMALL_CAP + 1>), dim3(fy), dim3(MG_BLOCK), 0, st, jobs, so, todo_list, todo_count);
         return;
     }
-    // continuation: enough workgroups per job to fill the chip, striding over chunks
-    uint32_t gx = (max_m + SEL_CHUNK - 1) / SEL_CHUNK;
+    // host-driven continuation (rare: more than `passes` wide passes needed, or more than 256 listed jobs)
     uint32_t cap = 4096 / njobs; if (cap < 4) cap = 4;
     if (gx <= SEL_SOLO_CHUNKS) gx = 1; else if (gx > cap) gx = cap;
     for (int p = 0; p < passes; p++)
-        hipLaunchKernelGGL(k_select_pass, dim3(gx, njobs), dim3(MG_BLOCK), 0, st, jobs, (const SelOut *)outs, 0);
-    hipLaunchKernelGGL((k_select_final<SEL_SMALL_CAP, 0>), dim3(njobs), dim3(MG_BLOCK), 0, st, jobs, (const SelOut *)outs);
-    hipLaunchKernelGGL((k_select_final<SEL_BIG_CAP, SEL_SMALL_CAP + 1>), dim3(njobs), dim3(MG_BLOCK), 0, st, jobs, (const SelOut *)outs);
+        hipLaunchKernelGGL(k_select_pass, dim3(gx, njobs), dim3(MG_BLOCK), 0, st, jobs, so, 0, nullptr, nullptr);
+    hipLaunchKernelGGL((k_select_final<SEL_SMALL_CAP, 0>), dim3(njobs), dim3(MG_BLOCK), 0, st, jobs, so, nullptr, nullptr);
+    hipLaunchKernelGGL((k_select_final<SEL_BIG_CAP, SEL_SMALL_CAP + 1>), dim3(njobs), dim3(MG_BLOCK), 0, st, jobs, so, nullptr, nullptr);
 }
 void mgk_row_op(hipStream_t st, const unsigned long long *a, const unsigned long long *b, unsigned long long *out,
                 uint32_t W, int op, unsigned long long *card) {
