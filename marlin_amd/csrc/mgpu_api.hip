@@ -580,6 +580,20 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
             q.num_fops = (int)(fo.size() / 2);
             blob.insert(blob.end(), fo.begin(), fo.end());
         }
+        // flattened plan for k_formula (staged into LDS by every workgroup)
+        {
+            std::vector<uint32_t> pl;
+            for (int t = 0; t < q.num_terms; t++) {
+                const uint32_t a0 = q.term_dense_off[t], a1 = q.term_dense_off[t + 1];
+                pl.push_back((a1 - a0) + (q.term_row[t] >= 0 ? 1u : 0u));
+                if (q.term_row[t] >= 0) pl.push_back((uint32_t)~q.term_row[t]);
+                for (uint32_t x = a0; x < a1; x++) pl.push_back(blob[x]);
+            }
+            q.plan_fops = (uint32_t)pl.size();
+            for (int j = 0; j < q.num_fops; j++) { pl.push_back(blob[q.fops_off + 2 * j]); pl.push_back(blob[q.fops_off + 2 * j + 1]); }
+            q.plan_off = (uint32_t)blob.size(); q.plan_len = (uint32_t)pl.size();
+            blob.insert(blob.end(), pl.begin(), pl.end());
+        }
         // wid table
         {
             uint32_t cap = 2; while (cap < 2 * p.num_wids + 2) cap <<= 1;

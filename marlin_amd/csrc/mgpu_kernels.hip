@@ -88,67 +88,108 @@ __global__ __launch_bounds__(MG_BLOCK) void k_scatter(const ScatterItem *items, 
 }
 
 // ------------------------------------------------------------------ formula + filter + popcount
-__device__ __forceinline__ u64 term_word(const SqDev &sq, const uint32_t *blob, int t, uint32_t w) {
-    u64 v = 0;
-    const int r = sq.term_row[t];
-    if (r >= 0) v = sq.rows[(size_t)r * sq.sh.Wp + w];
-    const uint32_t e = sq.term_dense_off[t + 1];
-    for (uint32_t i = sq.term_dense_off[t]; i < e; i++) v |= sq.sh.dense[(size_t)blob[i] * sq.sh.Wp + w];
-    return v;
+// get_matching_docids (squery.c:212-277) fused with squery_apply_filters (squery.c:377-395,
+// filter_apply.c:207-227) and bmap_cardinality (bmap.c:362-368).
+// A workgroup owns MG_FORMULA_WORDS consecutive u64 words of the squery's rows: it stages the
+// flattened plan (row list per term + filter program) into LDS once, then every lane streams
+// 2 x 16 bytes of each row (four words in flight per row step) and combines them in registers.
+#define MG_FORMULA_WORDS 1024
+#define MG_PLAN_LDS 1024
+struct W4 { u64 a, b, c, d; };
+__device__ __forceinline__ W4 w4_or(W4 x, W4 y) { return {x.a | y.a, x.b | y.b, x.c | y.c, x.d | y.d}; }
+__device__ __forceinline__ W4 w4_and(W4 x, W4 y) { return {x.a & y.a, x.b & y.b, x.c & y.c, x.d & y.d}; }
+__device__ __forceinline__ W4 w4_andnot(W4 x, W4 y) { return {x.a & ~y.a, x.b & ~y.b, x.c & ~y.c, x.d & ~y.d}; }
+__device__ __forceinline__ W4 w4_load(const u64 *row, uint32_t w0, uint32_t w1, bool in0, bool in1) {
+    // rows are padded to a multiple of 32 words (Wp), so a pair of words never straddles the end
+    const ulonglong2 z = make_ulonglong2(0ull, 0ull);
+    const ulonglong2 x = in0 ? *(const ulonglong2 *)(row + w0) : z;
+    const ulonglong2 y = in1 ? *(const ulonglong2 *)(row + w1) : z;
+    return {x.x, x.y, y.x, y.y};
 }
 
-// get_matching_docids (squery.c:212-277) fused with squery_apply_filters (squery.c:377-395,
-// filter_apply.c:207-227) and bmap_cardinality (bmap.c:362-368): one u64 word per lane.
 __global__ __launch_bounds__(MG_BLOCK) void k_formula(const SqDev *sqs, const uint32_t *blob) {
-    const SqDev &sq = sqs[blockIdx.y];
-    if (blockIdx.x >= sq.nblk) return;
-    __shared__ uint32_t red[MG_BLOCK / 64];
-    const uint32_t w = blockIdx.x * MG_WORDS_PER_BLOCK + threadIdx.x;
-    u64 v = 0;
-    if (w < sq.sh.W && !sq.empty) {
-        const int nt = sq.num_terms;
-        if (nt == 1) {
-            v = term_word(sq, blob, 0, w);
-        } else if (nt == 3) {
-            v = (term_word(sq, blob, 0, w) & term_word(sq, blob, 1, w)) | term_word(sq, blob, 2, w);
-        } else {
-            u64 acc = ~0ull, prev = 0;
+    const SqDev *sp = &sqs[blockIdx.y];
+    const uint32_t nblk = sp->nblk;                                  // 256-word blocks of the row
+    if (blockIdx.x * (MG_FORMULA_WORDS / MG_WORDS_PER_BLOCK) >= nblk) return;
+    // descriptor fields in one burst
+    const uint32_t Wp = sp->sh.Wp;
+    const int nt = sp->num_terms, nf = sp->num_fops, empty = sp->empty;
+    const uint32_t plan_off = sp->plan_off, plan_len = sp->plan_len, plan_fops = sp->plan_fops;
+    const u64 *dense = (const u64 *)sp->sh.dense;
+    const u64 *rows = (const u64 *)sp->rows;
+    u64 *docid_map = (u64 *)sp->docid_map;
+    uint32_t *blk_cnt = sp->blk_cnt;
+    __shared__ uint32_t s_plan[MG_PLAN_LDS];
+    __shared__ uint32_t red[8];
+    const uint32_t *plan = blob + plan_off;
+    const bool in_lds = plan_len <= MG_PLAN_LDS;
+    if (in_lds) {
+        for (uint32_t i = threadIdx.x; i < plan_len; i += MG_BLOCK) s_plan[i] = plan[i];
+        __syncthreads();
+    }
+    // lane -> words: [2t, 2t+1] of the first 512 words and of the second 512 words of the chunk
+    const uint32_t base = blockIdx.x * MG_FORMULA_WORDS;
+    const uint32_t w0 = base + 2 * threadIdx.x, w1 = w0 + 512;
+    const bool in0 = w0 < Wp, in1 = w1 < Wp;
+    W4 v = {0, 0, 0, 0};
+    if (!empty && in0) {
+        uint32_t p = 0;
+        auto word = [&](uint32_t i) -> uint32_t { return in_lds ? s_plan[i] : plan[i]; };
+        auto row_of = [&](uint32_t e) -> const u64 * {
+            return ((int32_t)e >= 0) ? dense + (size_t)e * Wp : rows + (size_t)(~e) * Wp;
+        };
+        auto term = [&]() -> W4 {
+            W4 t = {0, 0, 0, 0};
+            const uint32_t n = word(p++);
+            for (uint32_t j = 0; j < n; j++) t = w4_or(t, w4_load(row_of(word(p++)), w0, w1, in0, in1));
+            return t;
+        };
+        if (nt == 1) v = term();
+        else if (nt == 3) { const W4 t0 = term(), t1 = term(), t2 = term(); v = w4_or(w4_and(t0, t1), t2); }
+        else {
+            const W4 ones = {~0ull, ~0ull, ~0ull, ~0ull};
+            W4 acc = ones, prev = {0, 0, 0, 0};
             for (int i = 0; i < nt; i += 2) {
-                u64 g = prev | term_word(sq, blob, i, w);
-                u64 next = 0;
-                if (i < nt - 2) { next = term_word(sq, blob, i + 1, w); g |= next; }
-                acc &= g;
+                W4 g = w4_or(prev, term());
+                W4 next = {0, 0, 0, 0};
+                if (i < nt - 2) { next = term(); g = w4_or(g, next); }
+                acc = w4_and(acc, g);
                 prev = next;
             }
-            v = acc | term_word(sq, blob, nt - 1, w);
+            v = w4_or(acc, term());
         }
-        if (sq.num_fops > 0) {
+        if (nf > 0) {
             // postfix filter program on a small register stack (static indexing only)
-            u64 s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0;
-            const uint32_t *ops = blob + sq.fops_off;
-            for (int i = 0; i < sq.num_fops; i++) {
-                const int op = (int)ops[i * 2];
-                const int a = (int)ops[i * 2 + 1];
+            const W4 z = {0, 0, 0, 0};
+            W4 s0 = z, s1 = z, s2 = z, s3 = z, s4 = z, s5 = z, s6 = z, s7 = z;
+            for (int i = 0; i < nf; i++) {
+                const int op = (int)word(plan_fops + 2 * i);
+                const uint32_t a = word(plan_fops + 2 * i + 1);
                 if (op <= MGPU_F_PUSH_EMPTY) {
-                    u64 x = 0;
-                    if (op != MGPU_F_PUSH_EMPTY)
-                        x = (a >= 0) ? sq.sh.dense[(size_t)a * sq.sh.Wp + w] : sq.rows[(size_t)(~a) * sq.sh.Wp + w];
+                    W4 x = z;
+                    if (op != MGPU_F_PUSH_EMPTY) x = w4_load(row_of(a), w0, w1, in0, in1);
                     s7 = s6; s6 = s5; s5 = s4; s4 = s3; s3 = s2; s2 = s1; s1 = s0; s0 = x;
                 } else if (op == MGPU_F_DOCS_ANDNOT) {
-                    s0 = v & ~s0;
+                    s0 = w4_andnot(v, s0);
                 } else {
-                    s0 = (op == MGPU_F_AND) ? (s1 & s0) : (s1 | s0);
-                    s1 = s2; s2 = s3; s3 = s4; s4 = s5; s5 = s6; s6 = s7; s7 = 0;
+                    s0 = (op == MGPU_F_AND) ? w4_and(s1, s0) : w4_or(s1, s0);
+                    s1 = s2; s2 = s3; s3 = s4; s4 = s5; s5 = s6; s6 = s7; s7 = z;
                 }
             }
-            v &= s0;
+            v = w4_and(v, s0);
         }
     }
-    if (w < sq.sh.Wp) sq.docid_map[w] = v;
-    uint32_t c = wave_sum32((uint32_t)__popcll(v));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    if (in0) *(ulonglong2 *)(docid_map + w0) = make_ulonglong2(v.a, v.b);
+    if (in1) *(ulonglong2 *)(docid_map + w1) = make_ulonglong2(v.c, v.d);
+    // popcounts per 256-word block: wave k covers words [128k, 128k+128) of each half
+    const uint32_t c0 = wave_sum32((uint32_t)(__popcll(v.a) + __popcll(v.b)));
+    const uint32_t c1 = wave_sum32((uint32_t)(__popcll(v.c) + __popcll(v.d)));
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = c0; red[4 + (threadIdx.x >> 6)] = c1; }
     __syncthreads();
-    if (threadIdx.x == 0) sq.blk_cnt[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x < 4) {
+        const uint32_t b = blockIdx.x * (MG_FORMULA_WORDS / MG_WORDS_PER_BLOCK) + threadIdx.x;
+        if (b < nblk) blk_cnt[b] = red[2 * threadIdx.x] + red[2 * threadIdx.x + 1];
+    }
 }
 
 // exclusive scan of the per-block hit counts; one workgroup per squery
@@ -179,21 +220,37 @@ __global__ __launch_bounds__(MG_BLOCK) void k_scan(const SqDev *sqs, uint2 *tile
     for (uint32_t i = threadIdx.x; i < ntiles; i += MG_BLOCK) tile_list[s_base + i] = make_uint2(blockIdx.x, i);
 }
 
-// bmap_iterate / cont_iterate (bmap.c:370-374, cont.c:590-610): bitmap -> ascending docid list
-__global__ __launch_bounds__(MG_BLOCK) void k_compact(const SqDev *sqs) {
-    const SqDev &sq = sqs[blockIdx.y];
-    if (blockIdx.x >= sq.nblk) return;
-    __shared__ uint32_t lds[8];
-    const uint32_t w = blockIdx.x * MG_WORDS_PER_BLOCK + threadIdx.x;
-    u64 v = (w < sq.sh.W) ? sq.docid_map[w] : 0;
-    uint32_t tot;
-    uint32_t off = sq.blk_cnt[blockIdx.x] + block_excl_scan((uint32_t)__popcll(v), &tot, lds);
-    uint32_t base = w << 6;
+// bmap_iterate / cont_iterate (bmap.c:370-374, cont.c:590-610): bitmap -> ascending docid list.
+// Same work split as k_formula: 1024 words per workgroup, 2 x 16 bytes per lane.
+__device__ __forceinline__ void emit_bits(u64 v, uint32_t base, uint32_t *hits, uint32_t &off) {
     while (v) {
-        int b = __ffsll((long long)v) - 1;
+        const int b = __ffsll((long long)v) - 1;
         v &= v - 1;
-        sq.hits[off++] = base + (uint32_t)b;
+        hits[off++] = base + (uint32_t)b;
     }
+}
+__global__ __launch_bounds__(MG_BLOCK) void k_compact(const SqDev *sqs) {
+    const SqDev *sp = &sqs[blockIdx.y];
+    const uint32_t nblk = sp->nblk;
+    const uint32_t b0 = blockIdx.x * (MG_FORMULA_WORDS / MG_WORDS_PER_BLOCK);
+    if (b0 >= nblk) return;
+    const uint32_t Wp = sp->sh.Wp;
+    const u64 *docid_map = (const u64 *)sp->docid_map;
+    const uint32_t *blk_cnt = sp->blk_cnt;
+    uint32_t *hits = sp->hits;
+    __shared__ uint32_t lds[8];
+    const uint32_t w0 = blockIdx.x * MG_FORMULA_WORDS + 2 * threadIdx.x, w1 = w0 + 512;
+    const ulonglong2 z = make_ulonglong2(0ull, 0ull);
+    const ulonglong2 x = (w0 < Wp) ? *(const ulonglong2 *)(docid_map + w0) : z;
+    const ulonglong2 y = (w1 < Wp) ? *(const ulonglong2 *)(docid_map + w1) : z;
+    const uint32_t base0 = blk_cnt[b0];
+    const uint32_t base1 = (b0 + 2 < nblk) ? blk_cnt[b0 + 2] : 0;
+    uint32_t tot;
+    uint32_t off0 = base0 + block_excl_scan((uint32_t)(__popcll(x.x) + __popcll(x.y)), &tot, lds);
+    __syncthreads();
+    uint32_t off1 = base1 + block_excl_scan((uint32_t)(__popcll(y.x) + __popcll(y.y)), &tot, lds);
+    emit_bits(x.x, w0 << 6, hits, off0); emit_bits(x.y, (w0 + 1) << 6, hits, off0);
+    emit_bits(y.x, w1 << 6, hits, off1); emit_bits(y.y, (w1 + 1) << 6, hits, off1);
 }
 
 // ------------------------------------------------------------------ ranking
@@ -1271,9 +1328,9 @@ static uint32_t worklist_grid(uint32_t tile_cap) {
 }
 void mgk_formula(hipStream_t st, const SqDev *sqs, const uint32_t *blob, uint32_t max_nblk, uint32_t nsq,
                  uint2 *tile_list, uint32_t *tile_count) {
-    hipLaunchKernelGGL(k_formula, dim3(max_nblk, nsq), dim3(MG_BLOCK), 0, st, sqs, blob);
+    hipLaunchKernelGGL(k_formula, dim3((max_nblk + 3) / 4, nsq), dim3(MG_BLOCK), 0, st, sqs, blob);
     hipLaunchKernelGGL(k_scan, dim3(nsq), dim3(MG_BLOCK), 0, st, sqs, tile_list, tile_count);
-    hipLaunchKernelGGL(k_compact, dim3(max_nblk, nsq), dim3(MG_BLOCK), 0, st, sqs);
+    hipLaunchKernelGGL(k_compact, dim3((max_nblk + 3) / 4, nsq), dim3(MG_BLOCK), 0, st, sqs);
 }
 void mgk_rank(hipStream_t st, const SqDev *sqs, const uint32_t *blob, uint32_t max_n, uint32_t nsq,
               uint32_t max_tab_slots, const uint2 *tile_list, const uint32_t *tile_count, uint32_t tile_cap,

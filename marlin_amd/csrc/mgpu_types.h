@@ -81,6 +81,9 @@ struct SqDev {
     uint32_t term_dense_off[MGPU_MAX_TERMS + 1];   // into blob (u32 dense row indices)
     int32_t  term_row[MGPU_MAX_TERMS];             // scratch row index holding scattered sparse postings, or -1
     uint64_t *rows;                  // scratch rows [nrows][Wp], zeroed per query
+    // the same plan flattened for k_formula: per term {count, entries...}, entry >= 0 dense row, < 0 ~scratch row;
+    // then the filter ops {op, a} pairs.  plan_len u32 words at blob + plan_off.
+    uint32_t plan_off, plan_len, plan_fops;   // plan_fops: word index of the first filter op inside the plan
     // ---- filter ----
     int32_t  num_fops;
     uint32_t fops_off;               // into blob: 4 u32 per op {op, a, _, _}; operand a: dense row (>=0) or ~scratch row
