@@ -1,3 +1,5 @@
+#include <stdio.h>
+#include <stdlib.h>
 // mgpu_api.hip -- host runtime behind the C ABI of include/marlin_gpu.h.
 //
 // Mirror construction (reference formats -> HBM layouts), per-batch plan lowering, arena
@@ -832,6 +834,11 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
     if (!fkjobs.empty()) memcpy(c->pin + up_fk, fkjobs.data(), fkjobs.size() * sizeof(FkJob));
     if (!cardjobs.empty()) memcpy(c->pin + up_card, cardjobs.data(), cardjobs.size() * sizeof(CardJob));
 
+    if (getenv("MGPU_DEBUG")) {
+        uint64_t wids = 0; for (int i = 0; i < n; i++) wids += plans[i].num_wids;
+        fprintf(stderr, "[mgpu] n=%d zero=%.1fMB scratch=%.1fMB upload=%.2fMB results=%.2fMB max_tab=%u slots mean_wids=%.1f sel_jobs=%zu sizeof(SqDev)=%zu\n",
+                n, zero_bytes / 1e6, nz_bytes / 1e6, up_bytes / 1e6, res_bytes / 1e6, max_tab, (double)wids / n, seloff.size(), sizeof(SqDev));
+    }
     // ---------------- launches ----------------
     const double t_lowered = wall_ms();
     hipStream_t st = c->stream;

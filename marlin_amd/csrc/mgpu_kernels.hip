@@ -903,7 +903,7 @@ struct DigitPos { uint32_t e[MG_SEL_DIGIT]; int n; };
 __device__ __forceinline__ DigitPos load_digit_pos(const uint32_t *pos, int n) {
     DigitPos d; d.n = n;
 #pragma unroll
-    for (int j = 0; j < MG_SEL_DIGIT; j++) d.e[j] = pos[j];
+    for (int j = 0; j < MG_SEL_DIGIT; j++) d.e[j] = __builtin_amdgcn_readfirstlane(pos[j]);   // uniform: keep it in SGPRs
     return d;
 }
 __device__ __forceinline__ uint32_t digit_of(u64 hi, u64 lo, uint32_t idx, const DigitPos &p) {

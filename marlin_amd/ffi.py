@@ -95,6 +95,12 @@ class Result(C.Structure):
                 ("num_aggs", C.c_int), ("aggs", Agg * M_MAX_AGGS), ("full_scan", C.c_bool)]
 
 
+class Mirror(C.Structure):
+    """mmirror_t (marlin_amd/host/mplan.h): the posting-id scheme of one shard mirror"""
+    _fields_ = [("s", C.c_void_p), ("g", C.c_void_p), ("device", C.c_int), ("W", C.c_uint32), ("T", C.c_uint32),
+                ("fbase", C.c_uint32 * M_MAX_FIELDS), ("bbase", C.c_uint32), ("num_postings", C.c_uint32)]
+
+
 class ShardStruct(C.Structure):
     """leading fields of mshard_t that Python reads directly"""
     _fields_ = [("max_docid", C.c_uint32), ("num_strings", C.c_int), ("num_numbers", C.c_int),
@@ -171,6 +177,8 @@ def load():
         "mgpu_last_bytes": (ci, [vp, C.POINTER(C.c_uint64)]),
         "mgpu_stage_name": (C.c_char_p, [ci]),
         "mgpu_shard_bytes": (C.c_uint64, [vp]),
+        "mgpu_posting_op": (ci, [vp, vp, ci, cu, cu, C.POINTER(C.c_uint64), cu, C.POINTER(C.c_uint64)]),
+        "mshard_wid_posting": (C.c_uint64, [vp, cu, C.POINTER(C.POINTER(cu))]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)
