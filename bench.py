@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="queries per step")
     ap.add_argument("--cpu-queries", type=int, default=4)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--rehearse-gloo", action="store_true",
+                    help="multi-rank rehearsal on ONE GPU: gloo collectives on host tensors, every rank on cuda:0")
     ap.add_argument("--no-latency", action="store_true", help="skip the 200 single-query latency probes (cleaner kernel profiles)")
     ap.add_argument("--inflight", type=int, default=4, help="batches kept in flight per GPU (host threads x contexts)")
     args = ap.parse_args()
@@ -94,10 +96,15 @@ def main():
 
     import torch
     dist = None
+    if args.rehearse_gloo:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_gloo:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(local_rank)
 
@@ -127,7 +134,8 @@ def main():
     gather = None
     if world > 1:
         from marlin_amd.dist import ShardGather
-        gather = ShardGather(lib, dist, world, rank, B, local, K_TOP, NF, FMAX, NAGG, device="cuda:%d" % local_rank)
+        gather = ShardGather(lib, dist, world, rank, B, local, K_TOP, NF, FMAX, NAGG,
+                             device=None if args.rehearse_gloo else "cuda:%d" % local_rank)
 
     # Term lookup (the dtrie walk of lookup_terms) is outside the north-star path ("per-shard
     # query execution after term lookup"): resolve it once per distinct batch, before timing.
@@ -157,12 +165,15 @@ def main():
                     if gather_turn[0] < 0:
                         raise RuntimeError("another host thread failed")
                     order.wait()
-                sq = gather.gather(outs)             # one RCCL all_gather of fixed-size result slots
+                sq = gather.gather(outs, share=True)     # one RCCL all_gather of fixed-size result slots
                 gather_turn[0] += 1
                 order.notify_all()
-            if sq is not None:
-                hits = lib.m_form_result_batch(qarr, sq, B, TOTAL_SHARDS, None, 0)
-                gather.free(sq)
+            # every rank merges its own share of the batch's queries (the gather delivered all slots everywhere)
+            mine = gather.my_queries()
+            if mine:
+                qsub = (C.POINTER(ffi.Query) * len(mine))(*[pqs[i].q for i in mine])
+                hits = lib.m_form_result_batch(qsub, sq, len(mine), TOTAL_SHARDS, None, 0)
+            gather.free(sq)
         eng.free_raw(outs)
         return hits
 
@@ -203,7 +214,11 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        th = torch.tensor([float(total_hits)], dtype=torch.float64, device="cpu" if args.rehearse_gloo else "cuda")
+        dist.all_reduce(th)
+        total_hits = int(th.item())
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearse_gloo else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     qps = args.steps * B / dt

@@ -29,23 +29,40 @@ class ShardGather:
             self.recv = torch.empty(world * n, dtype=torch.uint8, device=device)
         self.torch = torch
 
-    def gather(self, outs):
-        """outs: ctypes SqResult array [query][local shard] of this rank.  Returns, on rank 0, a
-        SqResult array [query][global shard] the caller frees with free(); None elsewhere."""
+    def my_queries(self):
+        """indices of the batch's queries this rank merges when every rank takes a share"""
+        return list(range(self.rank, self.nq, self.world))
+
+    def gather(self, outs, share=False):
+        """outs: ctypes SqResult array [query][local shard] of this rank.
+        share=False: returns, on rank 0, a SqResult array [query][global shard] (None elsewhere).
+        share=True : every rank gets the [query][global shard] array of ITS share of the queries
+        (my_queries()): all_gather already delivers every slot everywhere, so the merge spreads over
+        the ranks with no further communication.  The caller frees the array with free()."""
         lib = self.lib
+        if self.on_gpu:
+            # the previous call's async copy out of host_send must have run before it is overwritten;
+            # wait on torch's stream only (a device-wide sync would stall the other contexts' batches)
+            self.torch.cuda.current_stream().synchronize()
         lib.m_slot_pack_batch(outs, self.nq * self.local, *self.shape, self.host_send.data_ptr())
         if self.on_gpu:
             self.send.copy_(self.host_send, non_blocking=True)
             self.dist.all_gather_into_tensor(self.recv, self.send)
-            if self.rank != 0:
+            if self.rank != 0 and not share:
                 return None
             self.host_recv.copy_(self.recv, non_blocking=True)
-            self.torch.cuda.synchronize()
+            self.torch.cuda.current_stream().synchronize()
         else:
             self.dist.all_gather_into_tensor(self.host_recv, self.host_send)
-            if self.rank != 0:
+            if self.rank != 0 and not share:
                 return None
         total = self.world * self.local
+        if share:
+            mine = len(self.my_queries())
+            sq = (ffi.SqResult * max(1, mine * total))()
+            lib.m_slot_unpack_gathered_subset(self.host_recv.data_ptr(), self.world, self.nq, self.local, *self.shape,
+                                              self.rank, self.world, sq)
+            return sq
         sq = (ffi.SqResult * (self.nq * total))()
         lib.m_slot_unpack_gathered(self.host_recv.data_ptr(), self.world, self.nq, self.local, *self.shape, sq)
         return sq

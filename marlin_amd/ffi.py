@@ -160,6 +160,7 @@ def load():
         "m_slot_bytes": (C.c_size_t, [ci, ci, ci, ci]),
         "m_slot_pack_batch": (None, [C.POINTER(SqResult), ci, ci, ci, ci, ci, vp]),
         "m_slot_unpack_gathered": (None, [vp, ci, ci, ci, ci, ci, ci, ci, C.POINTER(SqResult)]),
+        "m_slot_unpack_gathered_subset": (None, [vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, C.POINTER(SqResult)]),
         "m_form_result_batch": (C.c_long, [C.POINTER(C.POINTER(Query)), C.POINTER(SqResult), ci, ci, C.POINTER(Result), ci]),
         "mmirror_gpu": (vp, [vp]),
         "msq_execute_batch": (ci, [vp, C.POINTER(vp), ci, C.POINTER(C.POINTER(Query)), ci, ci, C.POINTER(SqResult)]),

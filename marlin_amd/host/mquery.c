@@ -434,6 +434,22 @@ void m_slot_unpack_gathered(const uint8_t *buf, int nranks, int nq, int local_sh
             }
 }
 
+/* the same for every q_step-th query starting at q_first (each rank of an N-rank job merges its own
+ * share of the batch out of the gathered slots): sq[i * total + shard] for the i-th selected query */
+void m_slot_unpack_gathered_subset(const uint8_t *buf, int nranks, int nq, int local_shards, int k, int num_facets,
+                                   int fmax, int num_aggs, int q_first, int q_step, m_sqresult_t *sq) {
+    size_t sb = m_slot_bytes(k, num_facets, fmax, num_aggs);
+    int total = nranks * local_shards;
+    int i = 0;
+    for (int q = q_first; q < nq; q += q_step, i++)
+        for (int r = 0; r < nranks; r++)
+            for (int s = 0; s < local_shards; s++) {
+                int shard = r * local_shards + s;
+                m_slot_unpack(buf + (((size_t)r * nq + q) * local_shards + s) * sb, k, num_facets, fmax, num_aggs,
+                              shard, &sq[(size_t)i * total + shard]);
+            }
+}
+
 /* returns the sum of total_hits over the batch (a checksum the launcher prints) */
 long m_form_result_batch(const m_query_t *const *queries, m_sqresult_t *sq, int nq, int num_shards,
                          m_result_t *outs, int keep) {

@@ -57,6 +57,22 @@ bool m_rank_lt(const m_docrank_t *a, const m_docrank_t *b, const int *rules);
 bool m_rank_lt_canonical(const m_docrank_t *a, const m_docrank_t *b, const int *rules);
 void m_rank_sort_canonical(m_docrank_t *a, size_t n, const int *rules);
 
+/* Result slots: fixed-size wire form of one shard's squery_result for the cross-GPU gather that
+ * replaces the in-process hand-off of query.c:319-383 (k rank records, fmax facet entries per
+ * facet field, num_aggs aggregation partials; cardinality id sets are not carried). */
+size_t m_slot_bytes(int k, int num_facets, int fmax, int num_aggs);
+void m_slot_pack(const m_sqresult_t *r, int k, int num_facets, int fmax, int num_aggs, uint8_t *buf);
+void m_slot_unpack(const uint8_t *buf, int k, int num_facets, int fmax, int num_aggs, int shard_idx, m_sqresult_t *out);
+void m_slot_pack_batch(const m_sqresult_t *rs, int n, int k, int num_facets, int fmax, int num_aggs, uint8_t *buf);
+/* gathered layout: [rank][query][local shard]; output sq[query * total_shards + shard] */
+void m_slot_unpack_gathered(const uint8_t *buf, int nranks, int nq, int local_shards, int k, int num_facets,
+                            int fmax, int num_aggs, m_sqresult_t *sq);
+void m_slot_unpack_gathered_subset(const uint8_t *buf, int nranks, int nq, int local_shards, int k, int num_facets,
+                                   int fmax, int num_aggs, int q_first, int q_step, m_sqresult_t *sq);
+/* form_result for nq queries; returns the sum of total_hits (a checksum) */
+long m_form_result_batch(const m_query_t *const *queries, m_sqresult_t *sq, int nq, int num_shards,
+                         m_result_t *outs, int keep);
+
 #ifdef __cplusplus
 }
 #endif

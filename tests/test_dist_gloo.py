@@ -38,6 +38,16 @@ if rank == 0:
     lib.m_form_result_batch(qarr, sq, nq, world, res, 1)
     print("RESULT " + json.dumps([result_view(res[i], pqs[i]) for i in range(nq)]))
     g.free(sq)
+# the shared-merge mode: every rank merges its own share of the queries
+for i, pq in enumerate(pqs):
+    assert orc.orc_execute_squery(ix.shards[rank], pq.q, rank, 0, C.byref(outs[i])) == 0
+sq2 = g.gather(outs, share=True)
+mine = g.my_queries()
+qsub = (C.POINTER(ffi.Query) * len(mine))(*[pqs[i].q for i in mine])
+res2 = (ffi.Result * len(mine))()
+lib.m_form_result_batch(qsub, sq2, len(mine), world, res2, 1)
+print("SHARE %d " % rank + json.dumps({str(q): result_view(res2[j], pqs[q]) for j, q in enumerate(mine)}))
+g.free(sq2)
 dist.barrier()
 dist.destroy_process_group()
 '''
@@ -112,4 +122,10 @@ def test_two_rank_gather_equals_single_process_merge(tmp_path):
     assert all(p.returncode == 0 for p in procs), outs
     line = [l for l in outs[0].splitlines() if l.startswith("RESULT ")][0]
     got = json.loads(line[len("RESULT "):])
-    assert got == json.loads(json.dumps(expect))
+    want = json.loads(json.dumps(expect))
+    assert got == want
+    shared = {}
+    for r in range(2):
+        l = [l for l in outs[r].splitlines() if l.startswith("SHARE %d " % r)][0]
+        shared.update(json.loads(l[len("SHARE %d " % r):]))
+    assert [shared[str(i)] for i in range(len(want))] == want
