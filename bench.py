@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--docs", type=int, default=10_000_000)
-    ap.add_argument("--batch", type=int, default=128, help="queries per step")
+    ap.add_argument("--batch", type=int, default=128, help="queries per step and GPU")
     ap.add_argument("--cpu-queries", type=int, default=4)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--rehearse-gloo", action="store_true",
@@ -122,9 +122,11 @@ def main():
     lib.msq_set_plan_threads(min(16, max(1, (os.cpu_count() or 8) // max(world, 1))))
     mirror_bytes = sum(lib.mgpu_shard_bytes(lib.mmirror_gpu(m)) for m in eng.mirrors)
 
-    nq_pool = 256
+    # queries per step grow with the number of GPUs so that a rank's batch (queries x its shards)
+    # keeps the same size: the corpus is fixed (strong scaling), the query stream is not
+    B = args.batch * world
+    nq_pool = max(256, 2 * B)
     pool = [ix.query(j) for j in make_queries(lib, nq_pool)]
-    B = args.batch
     K_TOP, NF, FMAX, NAGG = 10, 2, 20, 0
     slot_b = lib.m_slot_bytes(K_TOP, NF, FMAX, NAGG)
 
@@ -140,7 +142,7 @@ def main():
     # Term lookup (the dtrie walk of lookup_terms) is outside the north-star path ("per-shard
     # query execution after term lookup"): resolve it once per distinct batch, before timing.
     t0 = time.time()
-    nbatches = max(1, nq_pool // B) if nq_pool % B == 0 else nq_pool
+    nbatches = max(1, nq_pool // B)
     prepared = [eng.prepare(batch_queries(j)) for j in range(nbatches)]
     t_prepare = time.time() - t0
 
