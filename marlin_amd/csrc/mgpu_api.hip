@@ -56,6 +56,7 @@ struct mgpu_shard {
     // host-side facts used when lowering plans
     std::vector<int32_t> post_dense;    // per pid
     std::vector<uint64_t> post_off;     // sparse CSR offsets (per pid)
+    std::vector<uint32_t> post_card;    // docs per posting (bounds the hit count of a plan)
     uint64_t np_n[MGPU_MAX_FIELDS];
     double avg_dw;                      // mean docword entries per doc
     double avg_fv[MGPU_MAX_FIELDS];     // mean facet values per doc
@@ -111,6 +112,8 @@ extern "C" int mgpu_shard_create(int device, const mgpu_shard_desc_t *d, mgpu_sh
     {
         s->post_dense.assign(d->num_postings, -1);
         s->post_off.assign((size_t)d->num_postings + 1, 0);
+        s->post_card.assign(d->num_postings, 0);
+        for (uint32_t p = 0; p < d->num_postings; p++) s->post_card[p] = (uint32_t)std::min<uint64_t>(d->post_off[p + 1] - d->post_off[p], N);
         std::vector<uint32_t> sparse_doc;
         std::vector<uint32_t> dense_pids;
         for (uint32_t p = 0; p < d->num_postings; p++) {
@@ -499,7 +502,7 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
         q.num_words = p.num_words;
         q.empty = (p.has_filter && p.filter_null) ? 1 : 0;
         q.nblk = (sd.W + MG_WORDS_PER_BLOCK - 1) / MG_WORDS_PER_BLOCK;
-        max_nblk = std::max(max_nblk, q.nblk); max_N = std::max(max_N, sd.N);
+        max_nblk = std::max(max_nblk, q.nblk);
         h.formula_rows = 1; h.scatter_docs = 0;
 
         auto use_posting = [&](uint32_t pid, int *row_io, std::vector<uint32_t> *dense_list) -> int {
@@ -517,6 +520,7 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
 
         // terms (num_terms == 0 -> every used docid, shard.c:51-53)
         int nt = p.num_terms;
+        uint64_t tcard[MGPU_MAX_TERMS + 1] = {0};        // |term t| <= sum of its postings' sizes
         if (nt == 0) {
             q.num_terms = 1;
             q.term_dense_off[0] = (uint32_t)blob.size();
@@ -529,10 +533,13 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
             for (int t = 0; t < nt; t++) {
                 std::vector<uint32_t> dl;
                 int row = -1;
+                uint64_t tc = 0;
                 for (uint32_t j = 0; j < p.term_npost[t]; j++) {
                     int rc = use_posting(p.term_post[t][j], &row, &dl);
                     if (rc) return rc;
+                    tc += sh->post_card[p.term_post[t][j]];
                 }
+                tcard[t] = std::min<uint64_t>(tc, sd.N);
                 std::sort(dl.begin(), dl.end());
                 dl.erase(std::unique(dl.begin(), dl.end()), dl.end());
                 q.term_dense_off[t] = (uint32_t)blob.size();
@@ -541,6 +548,25 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
                 q.term_row[t] = row;
                 h.formula_rows += dl.size() + (row >= 0 ? 1 : 0);
             }
+        }
+        // Upper bound of the hit count from the match formula alone (a filter only removes hits): the
+        // per-hit arrays below are sized by it instead of by the shard.  k_scan checks the real count
+        // against it and reports MGPU_E_LIMIT rather than writing past an array if the bound were wrong.
+        {
+            uint64_t hb = sd.N;
+            if (q.empty) hb = 0;
+            else if (nt == 1) hb = tcard[0];
+            else if (nt == 3) hb = std::min(tcard[0], tcard[1]) + tcard[2];
+            else if (nt > 3) {
+                uint64_t mn = sd.N;
+                for (int g = 0; g < nt; g += 2) {
+                    uint64_t gs = tcard[g] + (g > 0 ? tcard[g - 1] : 0) + (g < nt - 2 ? tcard[g + 1] : 0);
+                    mn = std::min(mn, gs);
+                }
+                hb = mn + tcard[nt - 1];
+            }
+            q.hit_cap = (uint32_t)std::min<uint64_t>(hb, sd.N);
+            max_N = std::max(max_N, q.hit_cap);
         }
         // filter program
         if (p.has_filter && !p.filter_null) {
@@ -668,9 +694,10 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
         }
         o.andor = zer.take(32); o.ovfcnt = zer.take(4);
         o.docmap = nz.take((size_t)sd.Wp * 8); o.blk = nz.take((size_t)(q.nblk + 1) * 4);
-        o.hits = nz.take((size_t)sd.N * 4);
-        o.khi = nz.take((size_t)sd.N * 8); o.klo = nz.take((size_t)sd.N * 8);
-        o.ovfl = nz.take((size_t)sd.N * 4);
+        const size_t hc = std::max<size_t>(q.hit_cap, 1);
+        o.hits = nz.take(hc * 4);
+        o.khi = nz.take(hc * 8); o.klo = nz.take(hc * 8);
+        o.ovfl = nz.take(hc * 4);
         o.aggpart = nz.take((size_t)q.nproc_blocks * std::max(1, p.num_aggs) * sizeof(AggPart));
         for (int j = 0; j < h.nfac; j++) {
             int f = h.fac_field[j];
@@ -689,11 +716,11 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
         h.rank_job = -1;
         if (h.k) {
             h.rank_job = (int)seloff.size();
-            SelOff so; so.mcap = sd.N;
-            so.cand0 = nz.take((size_t)sd.N * 4); so.cand1 = nz.take((size_t)sd.N * 4);
+            SelOff so; so.mcap = q.hit_cap;
+            so.cand0 = nz.take(hc * 4); so.cand1 = nz.take(hc * 4);
             so.hist = zer.take(MG_SEL_BINS * 4); so.ctl = zer.take(SEL_WORDS * 4); so.outidx = nz.take((size_t)MG_SEL_FINAL * 4);
             seloff.push_back(so); jobfix.push_back({i, 0, 0});
-            max_selm = std::max(max_selm, sd.N);
+            max_selm = std::max(max_selm, q.hit_cap);
         }
         for (int j = 0; j < h.nfac; j++) {
             int f = h.fac_field[j];
@@ -708,7 +735,7 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
     }
     // batch-wide work list of hit tiles, filled by k_scan
     size_t tile_cap = 0;
-    for (int i = 0; i < n; i++) tile_cap += ((size_t)sqd[i].sh.N + MG_BLOCK - 1) / MG_BLOCK;
+    for (int i = 0; i < n; i++) tile_cap += ((size_t)sqd[i].hit_cap + MG_BLOCK - 1) / MG_BLOCK;
     if (tile_cap > 0xFFFFFFFFull) return fail(MGPU_E_LIMIT, "batch too large for the tile work list");
     const size_t off_tilecnt = zer.take(4, 4);
     const size_t off_todocnt = zer.take(4, 4);
@@ -910,7 +937,7 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
         mgpu_sqout_t &o = outs[i];
         const ResHdr *hdr = (const ResHdr *)(c->pin_out + h.hdr_off);
         o.num_hits = hdr->num_hits;
-        if (hdr->err) { o.status = -(int)hdr->err; worst = o.status; g_err = "device reported an error (position scratch pool exhausted)"; continue; }
+        if (hdr->err) { o.status = -(int)hdr->err; worst = o.status; g_err = hdr->err == (uint32_t)(-MGPU_E_LIMIT) ? "hit count above the planned bound" : "device reported an error (position scratch pool exhausted)"; continue; }
         const uint64_t M = hdr->num_hits;
         // ranks
         uint32_t rn = h.k ? hdr->rank_n : 0;

@@ -213,7 +213,11 @@ __global__ __launch_bounds__(MG_BLOCK) void k_scan(const SqDev *sqs, uint2 *tile
         if (threadIdx.x == 0) carry = c + tot;
         __syncthreads();
     }
-    const uint32_t M = carry;
+    uint32_t M = carry;
+    if (M > sq.hit_cap) {                // the host's bound was wrong: report, and touch no per-hit array
+        if (threadIdx.x == 0) atomicMax(sq.err, (uint32_t)(-MGPU_E_LIMIT));
+        M = 0;
+    }
     const uint32_t ntiles = (M + MG_BLOCK - 1) / MG_BLOCK;
     if (threadIdx.x == 0) { *sq.num_hits = M; s_base = ntiles ? atomicAdd(tile_count, ntiles) : 0; }
     __syncthreads();
@@ -238,6 +242,7 @@ __global__ __launch_bounds__(MG_BLOCK) void k_compact(const SqDev *sqs) {
     const u64 *docid_map = (const u64 *)sp->docid_map;
     const uint32_t *blk_cnt = sp->blk_cnt;
     uint32_t *hits = sp->hits;
+    if (*sp->num_hits == 0) return;      // nothing to list (or k_scan refused the squery)
     __shared__ uint32_t lds[8];
     const uint32_t w0 = blockIdx.x * MG_FORMULA_WORDS + 2 * threadIdx.x, w1 = w0 + 512;
     const ulonglong2 z = make_ulonglong2(0ull, 0ull);

@@ -92,7 +92,8 @@ struct SqDev {
     uint32_t *blk_cnt;               // [nblk + 1] counts, then exclusive offsets
     uint32_t nblk;
     uint32_t *num_hits;              // device word
-    uint32_t *hits;                  // [N] ascending docids
+    uint32_t *hits;                  // [hit_cap] ascending docids
+    uint32_t hit_cap;                // host-side upper bound of the hit count; sizes every per-hit array
     // ---- rank ----
     int32_t  do_rank;                // hits_per_page > 0 && num_words > 0
     int32_t  rank_by;
