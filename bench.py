@@ -268,8 +268,18 @@ def main():
     ach = acc[dom][1] / acc[dom][0] / 1e6          # bytes / ms -> GB/s
     KERNELS = {"rank": "k_rank_tile + k_rank_overflow", "select": "k_select_pass", "formula+compact": "k_formula + k_scan + k_compact",
                "facets+aggs": "k_docproc + k_aggfinal", "facet-keys": "k_fkeys + k_card", "scatter": "k_scatter"}
+    # HBM traffic of the dominant kernel comes from separate PMC passes (rocprofv3 cannot run inside the
+    # timed program): profiles/r01_pmc_fetch_write_per_launch.json, same command and batch size
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_per_launch.json")) as f:
+            pm = json.load(f)
+        if dom == "rank" and B == 128 and world == 1 and args.docs == 10_000_000:
+            traffic = pm["k_rank_tile_hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     roof = {"bound": "hbm", "kernel": KERNELS.get(dom, dom), "stage": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
             "launch_ms": round(acc[dom][0] / nprof, 4), "algorithmic_MB_per_launch": round(acc[dom][1] / nprof / 1e6, 3)}
 
     # ---- CPU baseline: the C oracle (port of the reference's execute_squery) on this host, 1 core
