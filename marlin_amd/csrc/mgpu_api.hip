@@ -624,7 +624,10 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
         }
         // wid table
         {
-            uint32_t cap = 2; while (cap < 2 * p.num_wids + 2) cap <<= 1;
+            // sparse while it fits LDS (load <= 1/8: a word that is not in the table almost always meets an
+            // empty slot on its first probe, which the rank kernel batches), else load <= 1/2
+            uint32_t cap = 2; while (cap < 8 * p.num_wids + 2) cap <<= 1;
+            if (cap > MG_LDS_HASH) { cap = 2; while (cap < 2 * p.num_wids + 2) cap <<= 1; }
             if (blob.size() & 1) blob.push_back(0);          // 8-byte aligned slots
             q.hash_off = (uint32_t)blob.size(); q.hash_mask = cap - 1;
             if (cap <= MG_LDS_HASH) max_tab = std::max(max_tab, cap);

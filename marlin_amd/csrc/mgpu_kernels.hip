@@ -497,7 +497,7 @@ __device__ __forceinline__ void or_key_bits(u64 *key_andor, u64 a, u64 b, u64 na
 // its records.  Documents with more matches or positions than the LDS slices hold go to the
 // overflow list and are ranked by k_rank_overflow.
 extern __shared__ uint2 dyn_tab[];
-__global__ __launch_bounds__(MG_BLOCK) void k_rank_tile(const SqDev *sqs, const uint32_t *blob,
+__global__ __launch_bounds__(MG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_rank_tile(const SqDev *sqs, const uint32_t *blob,
                                                         const uint2 *tile_list, const uint32_t *tile_count) {
     __shared__ uint32_t s_doc[MG_BLOCK], s_pbase[MG_BLOCK], s_cnt[MG_BLOCK], s_np[MG_BLOCK];
     __shared__ double s_val[MG_BLOCK];
@@ -549,12 +549,21 @@ __global__ __launch_bounds__(MG_BLOCK) void k_rank_tile(const SqDev *sqs, const 
             // two explicit probe paths: through a runtime-selected pointer the compiler would emit
             // flat loads (LDS or global decided per access) and wait on each one
             const bool tab_in_lds = do_rank && hmask < MG_LDS_HASH;
-            auto take = [&](uint32_t d, uint32_t wid, uint32_t info) {
+            auto record = [&](uint32_t d, uint32_t val, uint32_t info) {
+                const uint32_t r = atomicAdd(&s_cnt[d], 1u);
+                if (r < MG_MCAP) s_match[d * MG_MCAP + r] = make_uint2(val, info);
+            };
+            auto take = [&](uint32_t d, uint32_t wid, uint32_t info) {          // full probe (tails, global tables)
                 uint32_t val;
                 const bool found = tab_in_lds ? probe_wid(dyn_tab, hmask, wid, val) : probe_wid(gtab, hmask, wid, val);
-                if (found) {
-                    const uint32_t r = atomicAdd(&s_cnt[d], 1u);
-                    if (r < MG_MCAP) s_match[d * MG_MCAP + r] = make_uint2(val, info);
+                if (found) record(d, val, info);
+            };
+            // after a first probe that met another key: continue from the next slot
+            auto take_from = [&](uint32_t d, uint32_t wid, uint32_t info, uint32_t h) {
+                for (h = (h + 1) & hmask;; h = (h + 1) & hmask) {
+                    const uint2 e = dyn_tab[h];
+                    if (e.x == wid) { record(d, e.y, info); return; }
+                    if (e.x == 0) return;
                 }
             };
             for (int half = 0; half < 2; half++) {
@@ -564,33 +573,78 @@ __global__ __launch_bounds__(MG_BLOCK) void k_rank_tile(const SqDev *sqs, const 
                     const uint32_t doc = s_doc[grp * 16 + half * 8 + k];
                     v[k] = (doc != 0xFFFFFFFFu && gl < S16) ? rec[(size_t)doc * S16 + gl] : make_uint4(0u, 0u, 0u, 0u);
                 }
+                // headers (lane 0 of the group holds them), rank value, and which of the lane's two 8-byte
+                // slots are docword entries
+                uint32_t in_a = 0, in_b = 0, tail = 0;
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
                     const uint32_t d = grp * 16 + half * 8 + k;
                     const uint32_t h0 = __shfl(v[k].x, 0, 16), h1 = __shfl(v[k].y, 0, 16);
-                    const uint32_t h2 = __shfl(v[k].z, 0, 16), h3 = __shfl(v[k].w, 0, 16);
-                    const uint32_t nwords = h0 & 0xFFFFu, nin = h0 >> 16, ws = h3 >> 16;
+                    const uint32_t h3 = __shfl(v[k].w, 0, 16);
+                    const uint32_t nin = h0 >> 16, ws = h3 >> 16;
                     if (gl == 0) s_pbase[d] = h1;
                     if (val_in_rec && gl == (uint32_t)(1 + (rb >> 1))) {
                         const u64 bits = (rb & 1) ? (((u64)v[k].w << 32) | v[k].z) : (((u64)v[k].y << 32) | v[k].x);
                         s_val[d] = __longlong_as_double((long long)bits);
                     }
-                    if (!do_rank) continue;
                     const uint32_t s0 = 2 * gl;
-                    if (s0 >= ws && s0 < ws + nin) take(d, v[k].x, v[k].y);
-                    if (s0 + 1 >= ws && s0 + 1 < ws + nin) take(d, v[k].z, v[k].w);
-                    // records longer than 256 B, then the words that did not fit the record at all
-                    if (nin + ws > 32) {
-                        const uint32_t doc = s_doc[d];
-                        for (uint32_t c = 16 + gl; c < S16; c += 16) {
-                            const uint4 x = rec[(size_t)doc * S16 + c];
-                            if (2 * c >= ws && 2 * c < ws + nin) take(d, x.x, x.y);
-                            if (2 * c + 1 >= ws && 2 * c + 1 < ws + nin) take(d, x.z, x.w);
+                    if (s0 >= ws && s0 < ws + nin) in_a |= 1u << k;
+                    if (s0 + 1 >= ws && s0 + 1 < ws + nin) in_b |= 1u << k;
+                    if (nin + ws > 32 || (h0 & 0xFFFFu) > nin) tail |= 1u << k;
+                }
+                if (do_rank) {
+                    if (tab_in_lds) {
+                        // first probes of all sixteen entries issued together; the table is sparse, so they
+                        // settle nearly every word (empty slot = not a query word)
+#pragma unroll
+                        for (int q4 = 0; q4 < 8; q4 += 4) {
+                            uint2 pa[4], pb[4];
+#pragma unroll
+                            for (int k = 0; k < 4; k++) {
+                                pa[k] = dyn_tab[hash_wid(v[q4 + k].x) & hmask];
+                                pb[k] = dyn_tab[hash_wid(v[q4 + k].z) & hmask];
+                            }
+#pragma unroll
+                            for (int k = 0; k < 4; k++) {
+                                const uint32_t d = grp * 16 + half * 8 + q4 + k;
+                                const uint4 e = v[q4 + k];
+                                if ((in_a >> (q4 + k)) & 1u) {
+                                    if (pa[k].x == e.x) record(d, pa[k].y, e.y);
+                                    else if (pa[k].x != 0) take_from(d, e.x, e.y, hash_wid(e.x) & hmask);
+                                }
+                                if ((in_b >> (q4 + k)) & 1u) {
+                                    if (pb[k].x == e.z) record(d, pb[k].y, e.w);
+                                    else if (pb[k].x != 0) take_from(d, e.z, e.w, hash_wid(e.z) & hmask);
+                                }
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 8; k++) {
+                            const uint32_t d = grp * 16 + half * 8 + k;
+                            if ((in_a >> k) & 1u) take(d, v[k].x, v[k].y);
+                            if ((in_b >> k) & 1u) take(d, v[k].z, v[k].w);
                         }
                     }
-                    for (uint32_t j = nin + gl; j < nwords; j += 16) {
-                        const uint2 w2 = dw[h2 + (j - nin)];
-                        take(d, w2.x, w2.y);
+                    // records longer than 256 B, then the words that did not fit the record at all (rare)
+                    if (__any(tail != 0)) {
+#pragma unroll
+                        for (int k = 0; k < 8; k++) {
+                            if (!((tail >> k) & 1u)) continue;
+                            const uint32_t d = grp * 16 + half * 8 + k;
+                            const uint32_t doc = s_doc[d];
+                            const uint32_t h0 = __shfl(v[k].x, 0, 16), h2 = __shfl(v[k].z, 0, 16), h3 = __shfl(v[k].w, 0, 16);
+                            const uint32_t nin = h0 >> 16, ws = h3 >> 16, nwords_k = h0 & 0xFFFFu;
+                            for (uint32_t c = 16 + gl; c < S16; c += 16) {
+                                const uint4 x = rec[(size_t)doc * S16 + c];
+                                if (2 * c >= ws && 2 * c < ws + nin) take(d, x.x, x.y);
+                                if (2 * c + 1 >= ws && 2 * c + 1 < ws + nin) take(d, x.z, x.w);
+                            }
+                            for (uint32_t j = nin + gl; j < nwords_k; j += 16) {
+                                const uint2 w2 = dw[h2 + (j - nin)];
+                                take(d, w2.x, w2.y);
+                            }
+                        }
                     }
                 }
             }
