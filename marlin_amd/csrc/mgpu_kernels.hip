@@ -24,7 +24,7 @@ __device__ __forceinline__ uint32_t wave_sum32(uint32_t v) {
 }
 // ---- optional phase clocks (mgpu_debug_phases): cycles summed per phase over the active workgroups
 __device__ int mg_dbg_on = 0;
-__device__ unsigned long long mg_dbg_acc[16];
+__device__ unsigned long long mg_dbg_acc[24];
 #define DBG_T(var) const long long var = mg_dbg_on ? (long long)wall_clock64() : 0
 #define DBG_ADD(slot, a, b) do { if (mg_dbg_on && threadIdx.x == 0) atomicAdd(&mg_dbg_acc[slot], (unsigned long long)((b) - (a))); } while (0)
 #define DBG_MAX(slot, a, b, tag) do { if (mg_dbg_on && threadIdx.x == 0) atomicMax(&mg_dbg_acc[slot], ((unsigned long long)((b) - (a)) << 32) | (unsigned long long)(tag)); } while (0)
@@ -683,7 +683,7 @@ __global__ __launch_bounds__(MG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                 __syncthreads();
             }
         }
-        DBG_T(t3);
+        DBG_T(t3); DBG_ADD(16, t0, t3);
         u64 a = 0, b = 0, na = 0, nb = 0;
         if (valid) {
             RankOut ro = {0, 0, 0, 0, 0};
@@ -1234,8 +1234,11 @@ __device__ __forceinline__ void select_job(const SelJob &job, const SelOut &sel_
             uint32_t d = s_dstar, cum = s_cum;
             if (d >= nbins) { d = nbins - 1; cum = nkept; }
             // the final workgroup streams the kept list and sorts what passes the last decision
-            if (pass > 0 && nkept <= MG_SEL_FINAL) done = true;
-            else if (nkept <= SEL_SOLO_CHUNKS * SEL_CHUNK && nwin_total + cum <= MG_SEL_FINAL) done = true;
+            // stop as soon as what is left fits the final sort: the small in-place one whenever k allows
+            // it (a 512-element sort costs a fraction of the 4096-element one), else the big one
+            const uint32_t fin_cap = (job.k <= SEL_SMALL_CAP / 2) ? SEL_SMALL_CAP : MG_SEL_FINAL;
+            if (pass > 0 && nkept <= fin_cap && nwin_total + nkept <= 2 * fin_cap) done = true;
+            else if (nkept <= SEL_SOLO_CHUNKS * SEL_CHUNK && nwin_total + cum <= fin_cap) done = true;
             go_on = !done && sel_nblocks(nkept, gridDim.x) == 1;
             fused = done && nkept <= SEL_SOLO_CHUNKS * SEL_CHUNK && nwin_total + cum <= SEL_SMALL_CAP;
             d_fin = d;
@@ -1368,7 +1371,7 @@ int mgk_debug_clock_cal(unsigned long long *out3) {
 }
 // phase clocks: enable, and read + reset the 16 accumulators (100 MHz wall_clock64 ticks)
 int mgk_debug_phases(int on, unsigned long long *out16) {
-    unsigned long long z[16] = {0};
+    unsigned long long z[24] = {0};
     if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(mg_dbg_acc), sizeof(z)) != hipSuccess) return -1;
     if (hipMemcpyToSymbol(HIP_SYMBOL(mg_dbg_acc), z, sizeof(z)) != hipSuccess) return -1;
     if (hipMemcpyToSymbol(HIP_SYMBOL(mg_dbg_on), &on, sizeof(int)) != hipSuccess) return -1;
@@ -1433,7 +1436,7 @@ void mgk_select(hipStream_t st, const SelJob *jobs, const void *outs, uint32_t n
         // ... then the wide passes and stand-alone sorts for whatever landed on the to-do list (usually
         // nothing or a handful of heavy jobs; the launches are near-free when the list is empty)
         uint32_t wx = gx <= SEL_SOLO_CHUNKS ? 1 : (gx > 64 ? 64 : gx);
-        uint32_t wy = njobs < 32 ? njobs : 32;
+        uint32_t wy = njobs < 128 ? njobs : 128;
         for (int p = 0; p < passes; p++)
             hipLaunchKernelGGL(k_select_todo, dim3(wx, wy), dim3(MG_BLOCK), 0, st, jobs, so, todo_list, todo_count);
         uint32_t fy = njobs < 256 ? njobs : 256;

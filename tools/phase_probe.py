@@ -28,10 +28,11 @@ gpu.mgk_debug_phases(1, None)
 for _ in range(1):
     eng.free_raw(eng.execute_prepared(prep))
 print("stage ms (with phase clocks):", {k: round(x["ms"], 4) for k, x in eng.timing()["stages"].items()})
-out = (C.c_ulonglong * 16)()
+out = (C.c_ulonglong * 24)()
 gpu.mgk_debug_phases(0, out)
 v = list(out)
 tiles = max(1, v[3]); jobs = max(1, v[8])
+print("rank whole-before-phase2 per tile us: %.2f (setup + phase1 + phase1b)" % (v[16] / max(1, v[3]) / 100))
 print("rank tiles/launch", tiles / 1, "per-tile us: setup %.2f phase1 %.2f phase2 %.2f" % (v[0] / tiles / 100, v[1] / tiles / 100, v[2] / tiles / 100))
 print("select fused jobs/launch", jobs / 1, "us per WG (all WGs incl. idle contribute to setup): setup %.2f chunks %.2f decide %.2f final %.2f" % (v[4] / jobs / 100, v[5] / jobs / 100, v[6] / jobs / 100, v[7] / jobs / 100))
 for slot, name in ((13, "ANY exit WG"), (9, "whole WG"), (10, "final"), (11, "chunks"), (12, "setup")):
