@@ -29,7 +29,7 @@ void mgk_docproc(hipStream_t st, const SqDev *sqs, uint32_t nsq, const uint2 *ti
 void mgk_fkeys(hipStream_t st, const void *jobs, uint32_t njobs, uint32_t max_n);
 void mgk_card(hipStream_t st, const void *jobs, uint32_t njobs, uint32_t max_n);
 void mgk_select(hipStream_t st, const SelJob *jobs, const void *outs, uint32_t njobs, uint32_t max_m, int passes, int finals,
-                uint32_t *todo_list, uint32_t *todo_count);
+                void *items_mem, uint32_t cap_items, uint32_t *counters, uint32_t *fin_list);
 void mgk_row_op(hipStream_t st, const unsigned long long *a, const unsigned long long *b, unsigned long long *out,
                 uint32_t W, int op, unsigned long long *card);
 }
@@ -741,9 +741,14 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
     for (int i = 0; i < n; i++) tile_cap += ((size_t)sqd[i].hit_cap + MG_BLOCK - 1) / MG_BLOCK;
     if (tile_cap > 0xFFFFFFFFull) return fail(MGPU_E_LIMIT, "batch too large for the tile work list");
     const size_t off_tilecnt = zer.take(4, 4);
-    const size_t off_todocnt = zer.take(4, 4);
+    const size_t off_todocnt = zer.take(8 * 4, 8);            // select work-list counters
     const size_t off_tiles = nz.take(std::max<size_t>(tile_cap, 1) * sizeof(uint2));
-    const size_t off_todo = nz.take(std::max<size_t>(seloff.size(), 1) * 4 + 4);
+    const size_t off_todo = nz.take(std::max<size_t>(seloff.size(), 1) * 4 + 4);          // final list
+    // a job never asks for more than min(64, ceil(capacity / 2048)) workgroups per wide launch
+    size_t sel_items = 1;
+    for (const SelOff &so : seloff) sel_items += std::min<size_t>(64, ((size_t)so.mcap + 2047) / 2048);
+    const uint32_t sel_cap_items = (uint32_t)sel_items;
+    const size_t off_items = nz.take((size_t)sel_cap_items * 4 * sizeof(uint2));
     // scratch rows (zero region), now that row counts are known
     for (int i = 0; i < n; i++) offs[i].rows = zer.take((size_t)std::max(nrows[i], 1) * sqd[i].sh.Wp * 8);
 
@@ -895,7 +900,7 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
     mgk_card(st, UP + up_card, (uint32_t)cardjobs.size(), max_fk);
     mark();
     mgk_select(st, (const SelJob *)(UP + up_sel), UP + up_selout, (uint32_t)seljobs.size(), max_selm, MG_SEL_PASSES, 0,
-               (uint32_t *)(NZ + off_todo), (uint32_t *)(Z + off_todocnt));
+               NZ + off_items, sel_cap_items, (uint32_t *)(Z + off_todocnt), (uint32_t *)(NZ + off_todo));
     mark();
     HIPCHK(hipMemcpyAsync(c->pin_out, R, res_bytes, hipMemcpyDeviceToHost, st));
     if (prof) { (void)hipEventRecord(c->ev[evi++], st); } else { (void)hipEventRecord(c->ev[1], st); }
@@ -913,7 +918,7 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
             if (on == 0xFFFFFFFFu) again = true;
         }
         if (!again) break;
-        mgk_select(st, (const SelJob *)(UP + up_sel), UP + up_selout, (uint32_t)seljobs.size(), max_selm, MG_SEL_PASSES, 1, nullptr, nullptr);
+        mgk_select(st, (const SelJob *)(UP + up_sel), UP + up_selout, (uint32_t)seljobs.size(), max_selm, MG_SEL_PASSES, 1, nullptr, 0, nullptr, nullptr);
         HIPCHK(hipMemcpyAsync(c->pin_out, R, res_bytes, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
     }

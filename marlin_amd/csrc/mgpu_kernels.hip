@@ -985,11 +985,11 @@ __device__ __forceinline__ void job_masks(const SelJob &job, uint32_t M, u64 &mh
 
 #define SEL_ITEMS 8
 #define SEL_CHUNK (MG_BLOCK * SEL_ITEMS)     // candidates per workgroup iteration
-#define SEL_SOLO_CHUNKS 16                   // a lone workgroup takes lists up to 32768 and runs every remaining pass in one launch
+#define SEL_SOLO_CHUNKS 4                    // a lone workgroup takes lists up to 8192 and runs every remaining pass in one launch
 #define SEL_SMALL_CAP MG_SEL_SMALL            // final sort sizes: small / big workgroup variant
 #define SEL_BIG_CAP (2 * MG_SEL_FINAL)
 // extra ctl words used by the passes
-enum { SEL_NIN = SEL_NCAND, SEL_DSTAR = SEL_NEXT, SEL_BPREV = 8, SEL_NOUT = 9, SEL_BUF = 10, SEL_NPREV = 11, SEL_NFIN = 12 };
+enum { SEL_NIN = SEL_NCAND, SEL_DSTAR = SEL_NEXT, SEL_BPREV = 8, SEL_NOUT = 9, SEL_BUF = 10, SEL_NPREV = 11, SEL_NFIN = 12, SEL_NB = 13 };
 
 __device__ __forceinline__ uint32_t sel_nblocks(uint32_t nin, uint32_t gdim) {
     const uint32_t nch = (nin + SEL_CHUNK - 1) / SEL_CHUNK;
@@ -1070,8 +1070,21 @@ __device__ __forceinline__ void sel_final(const SelJob &job, const SelOut &out, 
 // workgroup (the common case: a shard's hits for one query) never come back to the host: that
 // workgroup keeps iterating passes in LDS until the answer fits the final sort, and when that
 // sort is small it does it on the spot (SEL_DONE = 2): no further launch touches the job.
-__device__ __forceinline__ void select_job(const SelJob &job, const SelOut &sel_out, int solo_only, uint32_t job_index,
-                                           uint32_t *todo_list, uint32_t *todo_count) {
+// Device-side work lists of the select stage (all in the batch arena):
+//   items[p] / nitems[p]: {job, workgroup index} pairs that the p-th wide launch runs (filled by the
+//   launch before it: a job asks for exactly the workgroups its current list needs);
+//   fin / nfin: jobs whose final set needs the stand-alone sort kernels.
+#define SEL_MAX_WG 64
+#define SEL_WIDE_LAUNCHES 3
+struct SelLists { uint2 *items[SEL_WIDE_LAUNCHES + 1]; uint32_t *nitems; uint32_t *fin; uint32_t *nfin; uint32_t cap_items; };
+enum { SELMODE_HOST = 0, SELMODE_FIRST = 1, SELMODE_ITEMS = 2 };
+
+// mode HOST : host-driven continuation, grid (gx, njobs): workgroup count from gridDim.x, vb = blockIdx.x
+// mode FIRST: first launch, one workgroup per job (vb = 0); too-long lists are handed to items[0]
+// mode ITEMS: wide launch `slot` over items[slot]; this workgroup is number vb of ctl[SEL_NB]
+__device__ __forceinline__ void select_job(const SelJob &job, const SelOut &sel_out, int mode, uint32_t job_index,
+                                           uint32_t vb, const SelLists &L, int slot) {
+    const int solo_only = mode == SELMODE_FIRST;
     uint32_t *ctl = job.ctl;
     const uint32_t M = *job.m_ptr;
     __shared__ u64 s_fhi[SEL_SMALL_CAP], s_flo[SEL_SMALL_CAP];
@@ -1079,7 +1092,7 @@ __device__ __forceinline__ void select_job(const SelJob &job, const SelOut &sel_
     DBG_T(ts0);
     DbgScope dbg_scope(13); dbg_scope.tag = M;
     // until a final sort has run the host must see "not finished"
-    if (blockIdx.x == 0 && threadIdx.x == 0 &&
+    if (vb == 0 && threadIdx.x == 0 &&
         __hip_atomic_load(&ctl[SEL_DONE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 2u) *job.out_n = 0xFFFFFFFFu;
     __shared__ uint32_t hist[MG_SEL_BINS];
     __shared__ uint32_t s_ctl[SEL_WORDS];
@@ -1089,8 +1102,9 @@ __device__ __forceinline__ void select_job(const SelJob &job, const SelOut &sel_
     u64 mhi, mlo; uint32_t midx;
     job_masks(job, M, mhi, mlo, midx);
     const int lane = threadIdx.x & 63;
-    uint32_t vbid = blockIdx.x;
+    uint32_t vbid = vb;
     bool continuing = false;
+    __shared__ uint32_t s_at;
 
     for (;;) {
         __syncthreads();
@@ -1100,11 +1114,11 @@ __device__ __forceinline__ void select_job(const SelJob &job, const SelOut &sel_
         const uint32_t pass = s_ctl[SEL_PASS];
         const uint32_t nin = (pass == 0) ? M : s_ctl[SEL_NIN];
         if (pass == 0 && (M <= SEL_SMALL_CAP || job.k >= M)) {
-            if (blockIdx.x != 0) return;
+            if (vb != 0) return;
             const bool small = M <= SEL_SMALL_CAP;
             if (threadIdx.x == 0) {
                 ctl[SEL_NIN] = M; ctl[SEL_KREM] = job.k; ctl[SEL_NFIN] = M; ctl[SEL_DONE] = small ? 2u : 1u;
-                if (!small && solo_only) todo_list[atomicAdd(todo_count, 1u)] = job_index;
+                if (!small && mode != SELMODE_HOST) L.fin[atomicAdd(L.nfin, 1u)] = job_index;
             }
             if (small) sel_final<SEL_SMALL_CAP>(job, sel_out, 0, M, 0, 0, nullptr, s_pcur, 0, s_fhi, s_flo, s_fix, s_fcnt);
             return;
@@ -1112,10 +1126,19 @@ __device__ __forceinline__ void select_job(const SelJob &job, const SelOut &sel_
         // first launch of a batch: one workgroup per job, lists beyond a lone workgroup's reach are
         // left for the continuation rounds (which bring a wider grid)
         if (solo_only && nin > SEL_SOLO_CHUNKS * SEL_CHUNK) {
-            if (blockIdx.x == 0 && threadIdx.x == 0) todo_list[atomicAdd(todo_count, 1u)] = job_index;
+            // ask for exactly the workgroups this list needs in the first wide launch
+            const uint32_t want = sel_nblocks(nin, SEL_MAX_WG);
+            if (threadIdx.x == 0) {
+                const uint32_t at = atomicAdd(&L.nitems[0], want);
+                s_at = (at + want <= L.cap_items) ? at : 0xFFFFFFFFu;       // no room: the host rounds pick the job up
+                ctl[SEL_NB] = want;
+            }
+            __syncthreads();
+            if (s_at != 0xFFFFFFFFu && threadIdx.x < want) L.items[0][s_at + threadIdx.x] = make_uint2(job_index, threadIdx.x);
             return;
         }
-        const uint32_t nb = sel_nblocks(nin, gridDim.x);
+        const uint32_t nb = continuing ? 1u : mode == SELMODE_ITEMS ? s_ctl[SEL_NB] : mode == SELMODE_FIRST ? 1u
+                                                                                       : sel_nblocks(nin, gridDim.x);
         if (!continuing && vbid >= nb) return;
         const bool solo = nb == 1;
 
@@ -1239,7 +1262,8 @@ __device__ __forceinline__ void select_job(const SelJob &job, const SelOut &sel_
             const uint32_t fin_cap = (job.k <= SEL_SMALL_CAP / 2) ? SEL_SMALL_CAP : MG_SEL_FINAL;
             if (pass > 0 && nkept <= fin_cap && nwin_total + nkept <= 2 * fin_cap) done = true;
             else if (nkept <= SEL_SOLO_CHUNKS * SEL_CHUNK && nwin_total + cum <= fin_cap) done = true;
-            go_on = !done && sel_nblocks(nkept, gridDim.x) == 1;
+            go_on = !done && (mode == SELMODE_HOST ? sel_nblocks(nkept, gridDim.x) == 1
+                                                   : nkept <= SEL_SOLO_CHUNKS * SEL_CHUNK);
             fused = done && nkept <= SEL_SOLO_CHUNKS * SEL_CHUNK && nwin_total + cum <= SEL_SMALL_CAP;
             d_fin = d;
             if (pass >= 1) newbuf = buf ^ (pass == 1 ? 0u : 1u);
@@ -1269,7 +1293,18 @@ __device__ __forceinline__ void select_job(const SelJob &job, const SelOut &sel_
             DBG_T(ts4); DBG_ADD(7, ts3, ts4); DBG_CNT(8); DBG_MAX(9, ts0, ts4, M); DBG_MAX(10, ts3, ts4, M); DBG_MAX(11, ts1, ts2, M); DBG_MAX(12, ts0, ts1, M);
             return;
         }
-        if (done && !fused && solo_only && threadIdx.x == 0) todo_list[atomicAdd(todo_count, 1u)] = job_index;
+        if (done && !fused && mode != SELMODE_HOST && threadIdx.x == 0) L.fin[atomicAdd(L.nfin, 1u)] = job_index;
+        if (!done && !go_on && mode == SELMODE_ITEMS && slot + 1 <= SEL_WIDE_LAUNCHES) {
+            // still too long for one workgroup: order the workgroups of the next wide launch
+            const uint32_t want = sel_nblocks(nkept, SEL_MAX_WG);
+            if (threadIdx.x == 0) {
+                const uint32_t at = atomicAdd(&L.nitems[slot + 1], want);
+                s_at = (at + want <= L.cap_items) ? at : 0xFFFFFFFFu;
+                ctl[SEL_NB] = want;
+            }
+            __syncthreads();
+            if (s_at != 0xFFFFFFFFu && threadIdx.x < want) L.items[slot + 1][s_at + threadIdx.x] = make_uint2(job_index, threadIdx.x);
+        }
         if (!go_on) return;
         // next pass in this launch: make this pass's list and control words visible to the whole workgroup
         __threadfence();
@@ -1277,22 +1312,21 @@ __device__ __forceinline__ void select_job(const SelJob &job, const SelOut &sel_
     }
 }
 
-// first launch of a batch: grid (1, njobs), one workgroup per job.  Jobs it cannot finish (lists
-// beyond a lone workgroup, final sets beyond the small sort) are put on the to-do list.
-__global__ __launch_bounds__(MG_BLOCK) void k_select_pass(const SelJob *jobs, const SelOut *outs, int solo_only,
-                                                          uint32_t *todo_list, uint32_t *todo_count) {
+// mode FIRST / HOST: grid (gx, njobs)
+__global__ __launch_bounds__(MG_BLOCK) void k_select_pass(const SelJob *jobs, const SelOut *outs, int mode, SelLists L) {
     const SelJob job = jobs[blockIdx.y];
-    select_job(job, outs[blockIdx.y], solo_only, blockIdx.y, todo_list, todo_count);
+    select_job(job, outs[blockIdx.y], mode, blockIdx.y, blockIdx.x, L, 0);
 }
-// the wide passes over the to-do list, enqueued behind the first launch without a host round trip:
-// grid (gx, gy), workgroup (x, y) is workgroup x of jobs todo[y], todo[y + gy], ...
-__global__ __launch_bounds__(MG_BLOCK) void k_select_todo(const SelJob *jobs, const SelOut *outs,
-                                                          const uint32_t *todo_list, const uint32_t *todo_count) {
-    const uint32_t n = *todo_count;
-    for (uint32_t y = blockIdx.y; y < n; y += gridDim.y) {
-        const uint32_t ji = todo_list[y];
+// wide launch `slot`: a 1-D grid strides over items[slot]; enqueued behind the first launch without a
+// host round trip, and nearly free when the list is empty
+__global__ __launch_bounds__(MG_BLOCK) void k_select_items(const SelJob *jobs, const SelOut *outs, SelLists L, int slot) {
+    uint32_t n = L.nitems[slot];
+    if (n > L.cap_items) n = L.cap_items;
+    for (uint32_t w = blockIdx.x; w < n; w += gridDim.x) {
+        const uint2 item = L.items[slot][w];
+        const uint32_t ji = __builtin_amdgcn_readfirstlane(item.x), vb = __builtin_amdgcn_readfirstlane(item.y);
         const SelJob job = jobs[ji];
-        select_job(job, outs[ji], 0, ji, nullptr, nullptr);
+        select_job(job, outs[ji], SELMODE_ITEMS, ji, vb, L, slot);
         __syncthreads();
     }
 }
@@ -1301,10 +1335,10 @@ __global__ __launch_bounds__(MG_BLOCK) void k_select_todo(const SelJob *jobs, co
 // needed several workgroups): one workgroup per job.  Two sizes of the same kernel.
 template <int CAP, int LO>
 __global__ __launch_bounds__(MG_BLOCK) void k_select_final(const SelJob *jobs, const SelOut *outs,
-                                                           const uint32_t *todo_list, const uint32_t *todo_count) {
-    // with a to-do list: one launch of min(njobs, 256) workgroups serves the listed jobs only
+                                                           const uint32_t *fin_list, const uint32_t *fin_count) {
+    // with a list: one launch of min(njobs, 256) workgroups serves the listed jobs only
     uint32_t ji = blockIdx.x;
-    if (todo_list) { if (blockIdx.x >= *todo_count) return; ji = todo_list[blockIdx.x]; }
+    if (fin_list) { if (blockIdx.x >= *fin_count) return; ji = fin_list[blockIdx.x]; }
     const SelJob job = jobs[ji];
     const uint32_t *ctl = job.ctl;
     const uint32_t M = *job.m_ptr;
@@ -1424,33 +1458,39 @@ void mgk_card(hipStream_t st, const void *jobs, uint32_t njobs, uint32_t max_n) 
 }
 // `finals` = 0: only the pass launches (jobs that fit one workgroup finish inside them);
 // 1: also the stand-alone final sorts, for the continuation rounds of larger jobs.
+// lists: device memory for the select work lists: nitems/nfin = 5 zeroed u32 words (4 item counters, then
+// the final-list counter), items = (SEL_WIDE_LAUNCHES + 1) arrays of cap_items uint2, fin = njobs u32.
 void mgk_select(hipStream_t st, const SelJob *jobs, const void *outs, uint32_t njobs, uint32_t max_m, int passes, int finals,
-                uint32_t *todo_list, uint32_t *todo_count) {
+                void *items_mem, uint32_t cap_items, uint32_t *counters, uint32_t *fin_list) {
     if (!njobs) return;
     const SelOut *so = (const SelOut *)outs;
+    SelLists L;
+    for (int i = 0; i <= SEL_WIDE_LAUNCHES; i++) L.items[i] = (uint2 *)items_mem + (size_t)i * cap_items;
+    L.nitems = counters; L.nfin = counters ? counters + 4 : nullptr; L.fin = fin_list; L.cap_items = cap_items;
     uint32_t gx = (max_m + SEL_CHUNK - 1) / SEL_CHUNK;
     if (!finals) {
         // first go: exactly one workgroup per job, no idle ones ...
-        hipLaunchKernelGGL(k_select_pass, dim3(1, njobs), dim3(MG_BLOCK), 0, st, jobs, so, 1, todo_list, todo_count);
-        if (gx <= SEL_SOLO_CHUNKS && max_m <= MG_SEL_SMALL) return;       // no job of this batch can end up on the list
-        // ... then the wide passes and stand-alone sorts for whatever landed on the to-do list (usually
-        // nothing or a handful of heavy jobs; the launches are near-free when the list is empty)
-        uint32_t wx = gx <= SEL_SOLO_CHUNKS ? 1 : (gx > 64 ? 64 : gx);
-        uint32_t wy = njobs < 128 ? njobs : 128;
-        for (int p = 0; p < passes; p++)
-            hipLaunchKernelGGL(k_select_todo, dim3(wx, wy), dim3(MG_BLOCK), 0, st, jobs, so, todo_list, todo_count);
+        hipLaunchKernelGGL(k_select_pass, dim3(1, njobs), dim3(MG_BLOCK), 0, st, jobs, so, (int)SELMODE_FIRST, L);
+        if (gx <= SEL_SOLO_CHUNKS && max_m <= MG_SEL_SMALL) return;       // no job of this batch can end up on a list
+        // ... then the wide launches over exactly the workgroups the long lists asked for, and the
+        // stand-alone sorts for the jobs on the final list
+        if (gx > SEL_SOLO_CHUNKS) {
+            uint32_t g = cap_items < 2048 ? cap_items : 2048;
+            for (int p = 0; p < SEL_WIDE_LAUNCHES; p++)
+                hipLaunchKernelGGL(k_select_items, dim3(g), dim3(MG_BLOCK), 0, st, jobs, so, L, p);
+        }
         uint32_t fy = njobs < 256 ? njobs : 256;
-        hipLaunchKernelGGL((k_select_final<SEL_SMALL_CAP, 0>), dim3(fy), dim3(MG_BLOCK), 0, st, jobs, so, todo_list, todo_count);
-        hipLaunchKernelGGL((k_select_final<SEL_BIG_CAP, SEL_SMALL_CAP + 1>), dim3(fy), dim3(MG_BLOCK), 0, st, jobs, so, todo_list, todo_count);
+        hipLaunchKernelGGL((k_select_final<SEL_SMALL_CAP, 0>), dim3(fy), dim3(MG_BLOCK), 0, st, jobs, so, L.fin, L.nfin);
+        hipLaunchKernelGGL((k_select_final<SEL_BIG_CAP, SEL_SMALL_CAP + 1>), dim3(fy), dim3(MG_BLOCK), 0, st, jobs, so, L.fin, L.nfin);
         return;
     }
-    // host-driven continuation (rare: more than `passes` wide passes needed, or more than 256 listed jobs)
+    // host-driven continuation (rare: more than SEL_WIDE_LAUNCHES wide passes needed, or a list overflowed)
     uint32_t cap = 4096 / njobs; if (cap < 4) cap = 4;
     if (gx <= SEL_SOLO_CHUNKS) gx = 1; else if (gx > cap) gx = cap;
     for (int p = 0; p < passes; p++)
-        hipLaunchKernelGGL(k_select_pass, dim3(gx, njobs), dim3(MG_BLOCK), 0, st, jobs, so, 0, nullptr, nullptr);
-    hipLaunchKernelGGL((k_select_final<SEL_SMALL_CAP, 0>), dim3(njobs), dim3(MG_BLOCK), 0, st, jobs, so, nullptr, nullptr);
-    hipLaunchKernelGGL((k_select_final<SEL_BIG_CAP, SEL_SMALL_CAP + 1>), dim3(njobs), dim3(MG_BLOCK), 0, st, jobs, so, nullptr, nullptr);
+        hipLaunchKernelGGL(k_select_pass, dim3(gx, njobs), dim3(MG_BLOCK), 0, st, jobs, so, (int)SELMODE_HOST, L);
+    hipLaunchKernelGGL((k_select_final<SEL_SMALL_CAP, 0>), dim3(njobs), dim3(MG_BLOCK), 0, st, jobs, so, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
+    hipLaunchKernelGGL((k_select_final<SEL_BIG_CAP, SEL_SMALL_CAP + 1>), dim3(njobs), dim3(MG_BLOCK), 0, st, jobs, so, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
 }
 void mgk_row_op(hipStream_t st, const unsigned long long *a, const unsigned long long *b, unsigned long long *out,
                 uint32_t W, int op, unsigned long long *card) {
