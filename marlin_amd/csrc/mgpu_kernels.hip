@@ -1002,10 +1002,12 @@ struct SelOut { u64 *out_hi, *out_lo; uint32_t *out_pl; const uint32_t *payload;
 // Final step of a selection, run by one workgroup: gather the winners the passes found and the
 // last candidate list with the last decision applied, bitonic-sort them by (hi, lo, idx) in LDS and
 // emit the first k.  s_cnt: two LDS words.
-template <int CAP>
+// REGS: the whole candidate list (one chunk) is still in the caller's registers: no second read of the keys
+template <int CAP, bool REGS = false>
 __device__ __forceinline__ void sel_final(const SelJob &job, const SelOut &out, uint32_t pass, uint32_t nin, uint32_t nwin,
                                           uint32_t dstar, const uint32_t *rin, const uint32_t *pprev_lds, int nprev,
-                                          u64 *s_hi, u64 *s_lo, uint32_t *s_ix, uint32_t *s_cnt) {
+                                          u64 *s_hi, u64 *s_lo, uint32_t *s_ix, uint32_t *s_cnt,
+                                          const uint32_t *ridx = nullptr, const u64 *rhi = nullptr, const u64 *rlo = nullptr) {
     if (threadIdx.x == 0) { s_cnt[0] = 0; s_cnt[1] = 0; }
     __syncthreads();
     const DigitPos pprev = load_digit_pos(pprev_lds, nprev);
@@ -1014,6 +1016,17 @@ __device__ __forceinline__ void sel_final(const SelJob &job, const SelOut &out, 
         const uint32_t p = atomicAdd(&s_cnt[0], 1u);
         if (p < CAP) { s_hi[p] = job.key_hi[idx]; s_lo[p] = job.key_lo[idx]; s_ix[p] = idx; }
     }
+    if (REGS) {
+#pragma unroll
+        for (int u = 0; u < SEL_ITEMS; u++) {
+            bool take = ridx[u] != 0xFFFFFFFFu;
+            if (take && pass > 0) take = digit_of(rhi[u], rlo[u], ridx[u], pprev) <= dstar;
+            if (take) {
+                const uint32_t p = atomicAdd(&s_cnt[0], 1u);
+                if (p < CAP) { s_hi[p] = rhi[u]; s_lo[p] = rlo[u]; s_ix[p] = ridx[u]; }
+            }
+        }
+    } else
     for (uint32_t i0 = threadIdx.x; i0 < nin; i0 += 4 * MG_BLOCK) {
         uint32_t idxs[4]; u64 his[4], los[4];
 #pragma unroll
@@ -1092,8 +1105,10 @@ __device__ __forceinline__ void select_job(const SelJob &job, const SelOut &sel_
     DBG_T(ts0);
     DbgScope dbg_scope(13); dbg_scope.tag = M;
     // until a final sort has run the host must see "not finished"
+    // (in the first launch the control words are known to be zero: the arena was just cleared)
     if (vb == 0 && threadIdx.x == 0 &&
-        __hip_atomic_load(&ctl[SEL_DONE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 2u) *job.out_n = 0xFFFFFFFFu;
+        (mode == SELMODE_FIRST || __hip_atomic_load(&ctl[SEL_DONE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 2u))
+        *job.out_n = 0xFFFFFFFFu;
     __shared__ uint32_t hist[MG_SEL_BINS];
     __shared__ uint32_t s_ctl[SEL_WORDS];
     __shared__ uint32_t s_scan[8];
@@ -1108,7 +1123,9 @@ __device__ __forceinline__ void select_job(const SelJob &job, const SelOut &sel_
 
     for (;;) {
         __syncthreads();
-        if (threadIdx.x < SEL_WORDS) s_ctl[threadIdx.x] = __hip_atomic_load(&ctl[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x < SEL_WORDS)
+            s_ctl[threadIdx.x] = (mode == SELMODE_FIRST && !continuing) ? 0u
+                               : __hip_atomic_load(&ctl[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         if (s_ctl[SEL_DONE]) return;
         const uint32_t pass = s_ctl[SEL_PASS];
@@ -1163,9 +1180,9 @@ __device__ __forceinline__ void select_job(const SelJob &job, const SelOut &sel_
         DBG_T(ts1); DBG_ADD(4, ts0, ts1);
 
         const uint32_t nch = (nin + SEL_CHUNK - 1) / SEL_CHUNK;
+        uint32_t idxs[SEL_ITEMS]; u64 his[SEL_ITEMS], los[SEL_ITEMS];       // outlive the loop: see the fused final below
         for (uint32_t ch = vbid; ch < nch; ch += nb) {
             // all loads of the chunk first (8 candidates per lane in flight), then the decisions
-            uint32_t idxs[SEL_ITEMS]; u64 his[SEL_ITEMS], los[SEL_ITEMS];
 #pragma unroll
             for (int it = 0; it < SEL_ITEMS; it++) {
                 const uint32_t i = ch * SEL_CHUNK + it * MG_BLOCK + threadIdx.x;
@@ -1288,8 +1305,12 @@ __device__ __forceinline__ void select_job(const SelJob &job, const SelOut &sel_
             // this workgroup is the only one left on the job: sort and emit right here
             __threadfence();
             __syncthreads();
-            sel_final<SEL_SMALL_CAP>(job, sel_out, pass + 1, nkept, nwin_total, d_fin,
-                                     (pass + 1 <= 1) ? nullptr : (newbuf ? job.cand[1] : job.cand[0]), s_pcur, ncur, s_fhi, s_flo, s_fix, s_fcnt);
+            if (pass == 0 && nch == 1 && solo)       // the only chunk is still in registers
+                sel_final<SEL_SMALL_CAP, true>(job, sel_out, 1, nkept, nwin_total, d_fin, nullptr, s_pcur, ncur,
+                                               s_fhi, s_flo, s_fix, s_fcnt, idxs, his, los);
+            else
+                sel_final<SEL_SMALL_CAP>(job, sel_out, pass + 1, nkept, nwin_total, d_fin,
+                                         (pass + 1 <= 1) ? nullptr : (newbuf ? job.cand[1] : job.cand[0]), s_pcur, ncur, s_fhi, s_flo, s_fix, s_fcnt);
             DBG_T(ts4); DBG_ADD(7, ts3, ts4); DBG_CNT(8); DBG_MAX(9, ts0, ts4, M); DBG_MAX(10, ts3, ts4, M); DBG_MAX(11, ts1, ts2, M); DBG_MAX(12, ts0, ts1, M);
             return;
         }
