@@ -743,7 +743,7 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
     const size_t off_tilecnt = zer.take(4, 4);
     const size_t off_todocnt = zer.take(8 * 4, 8);            // select work-list counters
     const size_t off_tiles = nz.take(std::max<size_t>(tile_cap, 1) * sizeof(uint2));
-    const size_t off_todo = nz.take(std::max<size_t>(seloff.size(), 1) * 4 + 4);          // final list
+    const size_t off_todo = nz.take(2 * (seloff.size() + 1) * 4);                         // final list, mid list
     // a job never asks for more than min(64, ceil(capacity / 2048)) workgroups per wide launch
     size_t sel_items = 1;
     for (const SelOff &so : seloff) sel_items += std::min<size_t>(64, ((size_t)so.mcap + 2047) / 2048);

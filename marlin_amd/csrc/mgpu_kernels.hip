@@ -30,14 +30,15 @@ __device__ unsigned long long mg_dbg_acc[24];
 #define DBG_MAX(slot, a, b, tag) do { if (mg_dbg_on && threadIdx.x == 0) atomicMax(&mg_dbg_acc[slot], ((unsigned long long)((b) - (a)) << 32) | (unsigned long long)(tag)); } while (0)
 struct DbgScope {       // records the longest lifetime of a workgroup (slot) with a tag, at every exit path
     long long t0; int slot; unsigned tag;
-    __device__ DbgScope(int s) : t0(mg_dbg_on ? (long long)wall_clock64() : 0), slot(s), tag(0) {}
-    __device__ ~DbgScope() { if (mg_dbg_on && threadIdx.x == 0) { long long t1 = (long long)wall_clock64(); atomicMax(&mg_dbg_acc[slot], ((unsigned long long)(t1 - t0) << 32) | tag);
+    __device__ __forceinline__ DbgScope(int s) : t0(mg_dbg_on ? (long long)wall_clock64() : 0), slot(s), tag(0) {}
+    __device__ __forceinline__ ~DbgScope() { if (mg_dbg_on && threadIdx.x == 0) { long long t1 = (long long)wall_clock64(); atomicMax(&mg_dbg_acc[slot], ((unsigned long long)(t1 - t0) << 32) | tag);
         atomicMax(&mg_dbg_acc[14], ~(unsigned long long)t0); atomicMax(&mg_dbg_acc[15], (unsigned long long)t1); } }
 };
 #define DBG_CNT(slot) do { if (mg_dbg_on && threadIdx.x == 0) atomicAdd(&mg_dbg_acc[slot], 1ull); } while (0)
 
 // exclusive scan of one u32 per thread over a 256-thread block; returns the block total in *total
-__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *total, uint32_t *lds /* >= 8 */) {
+template <int NT = MG_BLOCK>
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *total, uint32_t *lds /* >= NT / 64 */) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t incl = v;
 #pragma unroll
@@ -49,7 +50,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *total,
     __syncthreads();
     uint32_t base = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < MG_BLOCK / 64; w++) {
+    for (int w = 0; w < NT / 64; w++) {
         uint32_t s = lds[w];
         if (w < wave) base += s;
         tot += s;
@@ -983,6 +984,36 @@ __device__ __forceinline__ void job_masks(const SelJob &job, uint32_t M, u64 &mh
     midx = (M > 1) ? (0xFFFFFFFFu >> __clz(M - 1)) : 0u;
 }
 
+// Histogram update that survives skew: rank keys share most of their leading bits, so whole waves
+// tend to land in a handful of bins and plain LDS atomics would serialise on them.  Up to SEL_PEEL
+// times, the first pending lane's bin is counted for all lanes holding it (one atomic); whatever
+// is left after that goes one atomic per lane.
+#define SEL_PEEL 4
+__device__ __forceinline__ void hist_add(uint32_t *hist, bool alive, uint32_t digit) {
+    u64 rem = __ballot(alive);
+#pragma unroll
+    for (int r = 0; r < SEL_PEEL; r++) {
+        if (!rem) break;                                                    // wave-uniform
+        const int leader = __ffsll((long long)rem) - 1;
+        const uint32_t dl = (uint32_t)__builtin_amdgcn_readlane((int)digit, leader);
+        const u64 same = __ballot(alive && digit == dl);
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[dl], (uint32_t)__popcll(same));
+        alive = alive && digit != dl;
+        rem &= ~same;
+    }
+    if (alive) atomicAdd(&hist[digit], 1u);
+}
+// wave-aggregated slot allocation: position of this lane's element in a list counted by *counter
+__device__ __forceinline__ uint32_t wave_slot(bool pred, uint32_t *counter) {
+    const u64 m = __ballot(pred);
+    if (!m) return 0;
+    const int lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, __ffsll((long long)m) - 1);
+    return base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+}
+
 #define SEL_ITEMS 8
 #define SEL_CHUNK (MG_BLOCK * SEL_ITEMS)     // candidates per workgroup iteration
 #define SEL_SOLO_CHUNKS 4                    // a lone workgroup takes lists up to 8192 and runs every remaining pass in one launch
@@ -998,6 +1029,40 @@ __device__ __forceinline__ uint32_t sel_nblocks(uint32_t nin, uint32_t gdim) {
 }
 
 struct SelOut { u64 *out_hi, *out_lo; uint32_t *out_pl; const uint32_t *payload; };
+
+// bitonic sort of the s_cnt[0] keys gathered in LDS by (hi, lo, idx), then emit the first k
+template <int CAP, int NT = MG_BLOCK>
+__device__ __forceinline__ void sel_sort_emit(const SelJob &job, const SelOut &out, u64 *s_hi, u64 *s_lo, uint32_t *s_ix, uint32_t *s_cnt) {
+    __syncthreads();
+    const uint32_t n = s_cnt[0] < (uint32_t)CAP ? s_cnt[0] : (uint32_t)CAP;
+    uint32_t np2 = 1; while (np2 < n) np2 <<= 1;
+    for (uint32_t i = n + threadIdx.x; i < np2; i += NT) { s_hi[i] = ~0ull; s_lo[i] = ~0ull; s_ix[i] = 0xFFFFFFFFu; }
+    __syncthreads();
+    for (uint32_t k = 2; k <= np2; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < np2; i += NT) {
+                const uint32_t l = i ^ j;
+                if (l > i) {
+                    const bool up = (i & k) == 0;
+                    const u64 ah = s_hi[i], al = s_lo[i], bh = s_hi[l], bl = s_lo[l];
+                    const uint32_t ai = s_ix[i], bi = s_ix[l];
+                    const bool gt = (ah > bh) || (ah == bh && (al > bl || (al == bl && ai > bi)));
+                    if (gt == up) { s_hi[i] = bh; s_lo[i] = bl; s_ix[i] = bi; s_hi[l] = ah; s_lo[l] = al; s_ix[l] = ai; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const uint32_t kk = job.k < n ? job.k : n;
+    for (uint32_t i = threadIdx.x; i < kk; i += NT) {
+        if (job.skip_ones && s_hi[i] == ~0ull) continue;
+        out.out_hi[i] = s_hi[i]; out.out_lo[i] = s_lo[i];
+        out.out_pl[i] = out.payload ? out.payload[s_ix[i]] : s_ix[i];
+        atomicAdd(&s_cnt[1], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *job.out_n = s_cnt[1];
+}
 
 // Final step of a selection, run by one workgroup: gather the winners the passes found and the
 // last candidate list with the last decision applied, bitonic-sort them by (hi, lo, idx) in LDS and
@@ -1046,35 +1111,7 @@ __device__ __forceinline__ void sel_final(const SelJob &job, const SelOut &out, 
             }
         }
     }
-    __syncthreads();
-    const uint32_t n = s_cnt[0] < (uint32_t)CAP ? s_cnt[0] : (uint32_t)CAP;
-    uint32_t np2 = 1; while (np2 < n) np2 <<= 1;
-    for (uint32_t i = n + threadIdx.x; i < np2; i += MG_BLOCK) { s_hi[i] = ~0ull; s_lo[i] = ~0ull; s_ix[i] = 0xFFFFFFFFu; }
-    __syncthreads();
-    for (uint32_t k = 2; k <= np2; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = threadIdx.x; i < np2; i += MG_BLOCK) {
-                const uint32_t l = i ^ j;
-                if (l > i) {
-                    const bool up = (i & k) == 0;
-                    const u64 ah = s_hi[i], al = s_lo[i], bh = s_hi[l], bl = s_lo[l];
-                    const uint32_t ai = s_ix[i], bi = s_ix[l];
-                    const bool gt = (ah > bh) || (ah == bh && (al > bl || (al == bl && ai > bi)));
-                    if (gt == up) { s_hi[i] = bh; s_lo[i] = bl; s_ix[i] = bi; s_hi[l] = ah; s_lo[l] = al; s_ix[l] = ai; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-    const uint32_t kk = job.k < n ? job.k : n;
-    for (uint32_t i = threadIdx.x; i < kk; i += MG_BLOCK) {
-        if (job.skip_ones && s_hi[i] == ~0ull) continue;
-        out.out_hi[i] = s_hi[i]; out.out_lo[i] = s_lo[i];
-        out.out_pl[i] = out.payload ? out.payload[s_ix[i]] : s_ix[i];
-        atomicAdd(&s_cnt[1], 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) *job.out_n = s_cnt[1];
+    sel_sort_emit<CAP>(job, out, s_hi, s_lo, s_ix, s_cnt);
 }
 
 // One pass = filter the candidate list by the previous digit decision (winners below it go to the
@@ -1089,8 +1126,145 @@ __device__ __forceinline__ void sel_final(const SelJob &job, const SelOut &out, 
 //   fin / nfin: jobs whose final set needs the stand-alone sort kernels.
 #define SEL_MAX_WG 64
 #define SEL_WIDE_LAUNCHES 3
-struct SelLists { uint2 *items[SEL_WIDE_LAUNCHES + 1]; uint32_t *nitems; uint32_t *fin; uint32_t *nfin; uint32_t cap_items; };
+struct SelLists { uint2 *items[SEL_WIDE_LAUNCHES + 1]; uint32_t *nitems; uint32_t *fin; uint32_t *nfin; uint32_t cap_items;
+                  uint32_t *mid; uint32_t *nmid; };
 enum { SELMODE_HOST = 0, SELMODE_FIRST = 1, SELMODE_ITEMS = 2 };
+
+// The digit's bit positions folded into runs of adjacent bits inside one 32-bit word of the key
+// (word 0..3 = hi.hi, hi.lo, lo.hi, lo.lo, 4 = idx), MSB first: (word << 16 | low bit << 8 | length).
+// A run costs two instructions per key (bit-field extract, shift-or) where the per-bit form costs six.
+__device__ __forceinline__ int digit_runs(const uint32_t *pos, int n, uint32_t *runs) {
+    int nr = 0; uint32_t cw = 0, clow = 0, clen = 0;
+    for (int j = 0; j < n; j++) {
+        const uint32_t e = pos[j], w = e >> 8, sh = e & 0xFF;
+        const uint32_t w32 = (w == 2) ? 4u : (w * 2 + (sh >= 32 ? 0u : 1u)), bit = sh & 31u;
+        if (clen && w32 == cw && bit + 1 == clow) { clow = bit; clen++; }
+        else { if (clen) runs[nr++] = cw << 16 | clow << 8 | clen; cw = w32; clow = bit; clen = 1; }
+    }
+    if (clen) runs[nr++] = cw << 16 | clow << 8 | clen;
+    return nr;
+}
+
+// A fresh list that one workgroup can hold (M <= SEL_SOLO_CHUNKS * SEL_CHUNK) with a small k: the
+// whole selection in one go and without touching memory between passes.  Nothing is compacted:
+// every pass looks at all M keys again (from registers when they fit SEL_SOLO_REG chunks, else a
+// coalesced re-read that L2 serves) and keeps those whose decided prefix bits equal the prefix
+// chosen so far (pfx under mask msk, both over the varying bits consumed); the keys at or below the
+// last prefix are the final set.  Same decisions as the compacting passes, no lists, no fences.
+#define SEL_SOLO_REG 1
+#define SEL_MID_KEYS 131072u                            // longest fresh list that one 1024-thread workgroup selects (k_select_mid)
+#define SEL_MID_BLOCK 1024
+struct Pfx { u64 hi, lo; uint32_t ix; };
+template <int NT>
+__device__ __forceinline__ void select_solo(const SelJob &job, const SelOut &out, uint32_t M, u64 mhi, u64 mlo, uint32_t midx,
+                                            uint32_t *hist, uint32_t *s_scan, uint32_t *s_pcur, uint32_t *s_runs,
+                                            uint32_t *s_misc /* >= 6 */, u64 *s_fhi, u64 *s_flo, uint32_t *s_fix, uint32_t *s_fcnt) {
+    DBG_T(ts0);
+    constexpr int R = SEL_SOLO_REG * SEL_ITEMS;
+    constexpr uint32_t SEL_SOLO_GROUP = (uint32_t)R * NT;           // keys held in registers at a time
+    const uint32_t ngrp = (M + SEL_SOLO_GROUP - 1) / SEL_SOLO_GROUP;
+    const bool reg = ngrp == 1;
+    u64 rhi[R], rlo[R];
+#define SOLO_LOAD(g) do { _Pragma("unroll") for (int u = 0; u < R; u++) { \
+        const uint32_t i = (g) * SEL_SOLO_GROUP + u * NT + threadIdx.x; \
+        rhi[u] = (i < M) ? job.key_hi[i] : 0; rlo[u] = (i < M) ? job.key_lo[i] : 0; } } while (0)
+    if (reg) SOLO_LOAD(0);
+    Pfx pfx = {0, 0, 0}, msk = {0, 0, 0};
+    uint32_t bitpos = 0, nbelow = 0;                 // keys strictly below the prefix: all of them are in the top k
+    constexpr uint32_t BPT = MG_SEL_BINS / NT;
+    DBG_T(ts1); DBG_ADD(4, ts0, ts1);
+    for (;;) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < MG_SEL_BINS; i += NT) hist[i] = 0;
+        if (threadIdx.x == 0) {
+            uint32_t nb2;
+            const int nc = digit_bits(mhi, mlo, midx, bitpos, s_pcur, &nb2);
+            s_misc[0] = (uint32_t)nc; s_misc[5] = (uint32_t)digit_runs(s_pcur, nc, s_runs);
+            s_misc[1] = nb2; s_misc[2] = 0xFFFFFFFFu; s_misc[3] = 0; s_misc[4] = 0;
+        }
+        __syncthreads();
+        const int ncur = (int)__builtin_amdgcn_readfirstlane(s_misc[0]);
+        bitpos = __builtin_amdgcn_readfirstlane(s_misc[1]);
+        const int nruns = (int)__builtin_amdgcn_readfirstlane(s_misc[5]);
+        const DigitPos dcur = load_digit_pos(s_pcur, ncur);
+        DBG_T(tc0);
+        for (uint32_t g = 0; g < ngrp; g++) {
+            if (!reg) SOLO_LOAD(g);
+            uint32_t dg[R];
+#pragma unroll
+            for (int u = 0; u < R; u++) dg[u] = 0;
+            for (int r = 0; r < nruns; r++) {                       // uniform: the word choice is a scalar branch
+                const uint32_t e = __builtin_amdgcn_readfirstlane(s_runs[r]);
+                const uint32_t w32 = e >> 16, low = (e >> 8) & 0xFFu, len = e & 0xFFu;
+#define SOLO_RUN(expr) _Pragma("unroll") for (int u = 0; u < R; u++) dg[u] = (dg[u] << len) | __builtin_amdgcn_ubfe((uint32_t)(expr), low, len)
+                if (w32 == 0) { SOLO_RUN(rhi[u] >> 32); }
+                else if (w32 == 1) { SOLO_RUN(rhi[u]); }
+                else if (w32 == 2) { SOLO_RUN(rlo[u] >> 32); }
+                else if (w32 == 3) { SOLO_RUN(rlo[u]); }
+                else { SOLO_RUN(g * SEL_SOLO_GROUP + u * NT + threadIdx.x); }
+#undef SOLO_RUN
+            }
+#pragma unroll
+            for (int u = 0; u < R; u++) {
+                const uint32_t i = g * SEL_SOLO_GROUP + u * NT + threadIdx.x;
+                hist_add(hist, i < M && (rhi[u] & msk.hi) == pfx.hi && (rlo[u] & msk.lo) == pfx.lo && (i & msk.ix) == pfx.ix, dg[u]);
+            }
+        }
+        __syncthreads();
+        DBG_T(tc1); DBG_ADD(5, tc0, tc1);
+        // the bin where the running count of the surviving keys crosses what is still wanted
+        const uint32_t krem = job.k - nbelow;
+        uint32_t loc[BPT], lsum = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < BPT; j++) { loc[j] = hist[threadIdx.x * BPT + j]; lsum += loc[j]; }
+        uint32_t tot;
+        const uint32_t excl = block_excl_scan<NT>(lsum, &tot, s_scan);
+        if (excl < krem && excl + lsum >= krem) {
+            uint32_t acc = excl;
+#pragma unroll
+            for (uint32_t j = 0; j < BPT; j++) {
+                if (acc < krem && acc + loc[j] >= krem) { s_misc[2] = threadIdx.x * BPT + j; s_misc[3] = acc + loc[j]; s_misc[4] = acc; }
+                acc += loc[j];
+            }
+        }
+        __syncthreads();
+        uint32_t d = __builtin_amdgcn_readfirstlane(s_misc[2]), cum = __builtin_amdgcn_readfirstlane(s_misc[3]);
+        uint32_t below = __builtin_amdgcn_readfirstlane(s_misc[4]);
+        if (d >= (1u << ncur)) { d = (1u << ncur) - 1; cum = tot; below = tot; }       // cannot happen while k < M; stay in range
+        // extend the prefix by this digit
+#pragma unroll
+        for (int j = 0; j < MG_SEL_DIGIT; j++) {
+            if (j < ncur) {
+                const uint32_t e = dcur.e[j], w = e >> 8, sh = e & 0xFF, bit = (d >> (ncur - 1 - j)) & 1u;
+                if (w == 0) { msk.hi |= 1ull << sh; pfx.hi |= (u64)bit << sh; }
+                else if (w == 1) { msk.lo |= 1ull << sh; pfx.lo |= (u64)bit << sh; }
+                else { msk.ix |= 1u << sh; pfx.ix |= bit << sh; }
+            }
+        }
+        DBG_T(tc2); DBG_ADD(6, tc1, tc2);
+        if (nbelow + cum <= SEL_SMALL_CAP || ncur == 0) break;
+        nbelow += below;
+    }
+    // final set: every key at or below the prefix
+    DBG_T(tf0);
+    if (threadIdx.x == 0) { s_fcnt[0] = 0; s_fcnt[1] = 0; }
+    __syncthreads();
+    for (uint32_t g = 0; g < ngrp; g++) {
+        if (!reg) SOLO_LOAD(g);
+#pragma unroll
+        for (int u = 0; u < R; u++) {
+            const uint32_t i = g * SEL_SOLO_GROUP + u * NT + threadIdx.x;
+            const u64 a = rhi[u] & msk.hi, b = rlo[u] & msk.lo; const uint32_t c = i & msk.ix;
+            const bool take = i < M && (a < pfx.hi || (a == pfx.hi && (b < pfx.lo || (b == pfx.lo && c <= pfx.ix))));
+            const uint32_t p = wave_slot(take, &s_fcnt[0]);
+            if (take && p < SEL_SMALL_CAP) { s_fhi[p] = rhi[u]; s_flo[p] = rlo[u]; s_fix[p] = i; }
+        }
+    }
+#undef SOLO_LOAD
+    if (threadIdx.x == 0) job.ctl[SEL_DONE] = 2u;            // later launches and host rounds leave the job alone
+    sel_sort_emit<SEL_SMALL_CAP, NT>(job, out, s_fhi, s_flo, s_fix, s_fcnt);
+    DBG_T(tf1); DBG_ADD(7, tf0, tf1); DBG_CNT(8); DBG_MAX(9, ts0, tf1, M); DBG_MAX(10, tf0, tf1, M);
+}
 
 // mode HOST : host-driven continuation, grid (gx, njobs): workgroup count from gridDim.x, vb = blockIdx.x
 // mode FIRST: first launch, one workgroup per job (vb = 0); too-long lists are handed to items[0]
@@ -1220,7 +1394,7 @@ __device__ __forceinline__ void select_job(const SelJob &job, const SelOut &sel_
                     if (keep) rout[bk + (uint32_t)__popcll(mk & below)] = idx;
                     if (winner) win[bw + (uint32_t)__popcll(mw & below)] = idx;
                 }
-                if (keep) atomicAdd(&hist[digit_of(hi, lo, idx, dcur)], 1u);
+                hist_add(hist, keep, digit_of(hi, lo, idx, dcur));
             }
         }
         __syncthreads();
@@ -1337,6 +1511,75 @@ __device__ __forceinline__ void select_job(const SelJob &job, const SelOut &sel_
 __global__ __launch_bounds__(MG_BLOCK) void k_select_pass(const SelJob *jobs, const SelOut *outs, int mode, SelLists L) {
     const SelJob job = jobs[blockIdx.y];
     select_job(job, outs[blockIdx.y], mode, blockIdx.y, blockIdx.x, L, 0);
+}
+// First launch of a batch's select stage: one workgroup per job, control words known to be zero (the
+// arena was just cleared).  Short lists are sorted outright, lists one workgroup can hold are selected
+// by select_solo, everything else asks for its workgroups in the first wide launch (a list that fits
+// one workgroup but wants a big k goes there too, as a one-workgroup item).
+__global__ __launch_bounds__(MG_BLOCK) void k_select_first(const SelJob *jobs, const SelOut *outs, SelLists L) {
+    const uint32_t ji = blockIdx.x;
+    const SelJob job = jobs[ji];
+    const SelOut out = outs[ji];
+    const uint32_t M = *job.m_ptr;
+    __shared__ u64 s_fhi[SEL_SMALL_CAP], s_flo[SEL_SMALL_CAP];
+    __shared__ uint32_t s_fix[SEL_SMALL_CAP], s_fcnt[2];
+    __shared__ uint32_t hist[MG_SEL_BINS];
+    __shared__ uint32_t s_scan[8], s_pcur[MG_SEL_DIGIT], s_runs[MG_SEL_DIGIT], s_misc[8];
+    DbgScope dbg_scope(13); dbg_scope.tag = M;
+    if (M <= SEL_SMALL_CAP) {
+        if (threadIdx.x == 0) { job.ctl[SEL_NIN] = M; job.ctl[SEL_KREM] = job.k; job.ctl[SEL_NFIN] = M; job.ctl[SEL_DONE] = 2u; }
+        sel_final<SEL_SMALL_CAP>(job, out, 0, M, 0, 0, nullptr, s_pcur, 0, s_fhi, s_flo, s_fix, s_fcnt);
+        return;
+    }
+    if (threadIdx.x == 0) *job.out_n = 0xFFFFFFFFu;          // until a final sort has run the host must see "not finished"
+    if (job.k >= M) {                                         // everything is wanted: the big stand-alone sort
+        if (threadIdx.x == 0) {
+            job.ctl[SEL_NIN] = M; job.ctl[SEL_KREM] = job.k; job.ctl[SEL_NFIN] = M; job.ctl[SEL_DONE] = 1u;
+            L.fin[atomicAdd(L.nfin, 1u)] = ji;
+        }
+        return;
+    }
+    if (M <= SEL_SOLO_CHUNKS * SEL_CHUNK && job.k <= SEL_SMALL_CAP / 2) {
+        u64 mhi, mlo; uint32_t midx;
+        job_masks(job, M, mhi, mlo, midx);
+        select_solo<MG_BLOCK>(job, out, M, mhi, mlo, midx, hist, s_scan, s_pcur, s_runs, s_misc, s_fhi, s_flo, s_fix, s_fcnt);
+        return;
+    }
+    if (M <= SEL_MID_KEYS && job.k <= SEL_SMALL_CAP / 2) {    // same selection by a 1024-thread workgroup of k_select_mid
+        if (threadIdx.x == 0) L.mid[atomicAdd(L.nmid, 1u)] = ji;
+        return;
+    }
+    const uint32_t want = sel_nblocks(M, SEL_MAX_WG);
+    if (mg_dbg_on && threadIdx.x == 0) {
+        atomicAdd(&mg_dbg_acc[17], 1ull); atomicAdd(&mg_dbg_acc[18], (unsigned long long)M);
+        atomicMax(&mg_dbg_acc[19], (unsigned long long)M); atomicAdd(&mg_dbg_acc[20], (unsigned long long)want);
+        if (job.skip_ones) atomicAdd(&mg_dbg_acc[21], 1ull);
+    }
+    if (threadIdx.x == 0) {
+        const uint32_t at = atomicAdd(&L.nitems[0], want);
+        s_misc[0] = (at + want <= L.cap_items) ? at : 0xFFFFFFFFu;       // no room: the host rounds pick the job up
+        job.ctl[SEL_NB] = want;
+    }
+    __syncthreads();
+    if (s_misc[0] != 0xFFFFFFFFu && threadIdx.x < want) L.items[0][s_misc[0] + threadIdx.x] = make_uint2(ji, threadIdx.x);
+}
+// The lists k_select_first found too long for 256 threads but short enough for one big workgroup:
+// select_solo again, four times the lanes.  A small grid strides over the list.
+__global__ __launch_bounds__(SEL_MID_BLOCK) void k_select_mid(const SelJob *jobs, const SelOut *outs, SelLists L) {
+    __shared__ u64 s_fhi[SEL_SMALL_CAP], s_flo[SEL_SMALL_CAP];
+    __shared__ uint32_t s_fix[SEL_SMALL_CAP], s_fcnt[2];
+    __shared__ uint32_t hist[MG_SEL_BINS];
+    __shared__ uint32_t s_scan[SEL_MID_BLOCK / 64], s_pcur[MG_SEL_DIGIT], s_runs[MG_SEL_DIGIT], s_misc[8];
+    const uint32_t n = *L.nmid;
+    for (uint32_t w = blockIdx.x; w < n; w += gridDim.x) {
+        const uint32_t ji = L.mid[w];
+        const SelJob job = jobs[ji];
+        const uint32_t M = *job.m_ptr;
+        u64 mhi, mlo; uint32_t midx;
+        job_masks(job, M, mhi, mlo, midx);
+        select_solo<SEL_MID_BLOCK>(job, outs[ji], M, mhi, mlo, midx, hist, s_scan, s_pcur, s_runs, s_misc, s_fhi, s_flo, s_fix, s_fcnt);
+        __syncthreads();
+    }
 }
 // wide launch `slot`: a 1-D grid strides over items[slot]; enqueued behind the first launch without a
 // host round trip, and nearly free when the list is empty
@@ -1479,8 +1722,9 @@ void mgk_card(hipStream_t st, const void *jobs, uint32_t njobs, uint32_t max_n) 
 }
 // `finals` = 0: only the pass launches (jobs that fit one workgroup finish inside them);
 // 1: also the stand-alone final sorts, for the continuation rounds of larger jobs.
-// lists: device memory for the select work lists: nitems/nfin = 5 zeroed u32 words (4 item counters, then
-// the final-list counter), items = (SEL_WIDE_LAUNCHES + 1) arrays of cap_items uint2, fin = njobs u32.
+// lists: device memory for the select work lists: counters = 6 zeroed u32 words (4 item counters, the
+// final-list counter, the mid-list counter), items = (SEL_WIDE_LAUNCHES + 1) arrays of cap_items uint2,
+// fin_list = 2 * (njobs + 1) u32 (final list, then mid list).
 void mgk_select(hipStream_t st, const SelJob *jobs, const void *outs, uint32_t njobs, uint32_t max_m, int passes, int finals,
                 void *items_mem, uint32_t cap_items, uint32_t *counters, uint32_t *fin_list) {
     if (!njobs) return;
@@ -1488,14 +1732,17 @@ void mgk_select(hipStream_t st, const SelJob *jobs, const void *outs, uint32_t n
     SelLists L;
     for (int i = 0; i <= SEL_WIDE_LAUNCHES; i++) L.items[i] = (uint2 *)items_mem + (size_t)i * cap_items;
     L.nitems = counters; L.nfin = counters ? counters + 4 : nullptr; L.fin = fin_list; L.cap_items = cap_items;
+    L.nmid = counters ? counters + 5 : nullptr; L.mid = fin_list ? fin_list + njobs + 1 : nullptr;
     uint32_t gx = (max_m + SEL_CHUNK - 1) / SEL_CHUNK;
     if (!finals) {
         // first go: exactly one workgroup per job, no idle ones ...
-        hipLaunchKernelGGL(k_select_pass, dim3(1, njobs), dim3(MG_BLOCK), 0, st, jobs, so, (int)SELMODE_FIRST, L);
-        if (gx <= SEL_SOLO_CHUNKS && max_m <= MG_SEL_SMALL) return;       // no job of this batch can end up on a list
+        hipLaunchKernelGGL(k_select_first, dim3(njobs), dim3(MG_BLOCK), 0, st, jobs, so, L);
+        if (max_m <= MG_SEL_SMALL) return;                                 // no job of this batch can end up on a list
+        if (max_m > SEL_SOLO_CHUNKS * SEL_CHUNK)
+            hipLaunchKernelGGL(k_select_mid, dim3(njobs < 256 ? njobs : 256), dim3(SEL_MID_BLOCK), 0, st, jobs, so, L);
         // ... then the wide launches over exactly the workgroups the long lists asked for, and the
         // stand-alone sorts for the jobs on the final list
-        if (gx > SEL_SOLO_CHUNKS) {
+        if (cap_items) {
             uint32_t g = cap_items < 2048 ? cap_items : 2048;
             for (int p = 0; p < SEL_WIDE_LAUNCHES; p++)
                 hipLaunchKernelGGL(k_select_items, dim3(g), dim3(MG_BLOCK), 0, st, jobs, so, L, p);

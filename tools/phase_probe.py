@@ -17,8 +17,9 @@ shards = bench.build_shards(lib, 10_000_000, list(range(8)))
 ix = Index.from_shards({}, shards, ["str"], ["num", "price"], ["flag"], ["cat", "hc"])
 eng = GpuEngine(ix, device=0)
 lib.msq_set_plan_threads(16)
-pool = [ix.query(j) for j in bench.make_queries(lib, 64)]
-prep = eng.prepare(pool[:32])
+NB = int(os.environ.get("PROBE_BATCH", "32"))
+pool = [ix.query(j) for j in bench.make_queries(lib, NB)]
+prep = eng.prepare(pool[:NB])
 for _ in range(3):
     eng.free_raw(eng.execute_prepared(prep))
 eng.set_profiling(True)
@@ -37,6 +38,7 @@ print("rank tiles/launch", tiles / 1, "per-tile us: setup %.2f phase1 %.2f phase
 print("select fused jobs/launch", jobs / 1, "us per WG (all WGs incl. idle contribute to setup): setup %.2f chunks %.2f decide %.2f final %.2f" % (v[4] / jobs / 100, v[5] / jobs / 100, v[6] / jobs / 100, v[7] / jobs / 100))
 for slot, name in ((13, "ANY exit WG"), (9, "whole WG"), (10, "final"), (11, "chunks"), (12, "setup")):
     print("select max %s: %.1f us at M=%d" % (name, (v[slot] >> 32) / 100, v[slot] & 0xFFFFFFFF))
+print("wide select jobs %d (facet jobs %d), sum M %d, max M %d, workgroups asked %d" % (v[17], v[21], v[18], v[19], v[20]))
 cal = (C.c_ulonglong * 3)()
 gpu.mgk_debug_clock_cal.argtypes = [C.POINTER(C.c_ulonglong)]
 gpu.mgk_debug_clock_cal(cal)
