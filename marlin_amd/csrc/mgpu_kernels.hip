@@ -1160,6 +1160,7 @@ __device__ __forceinline__ void select_solo(const SelJob &job, const SelOut &out
                                             uint32_t *hist, uint32_t *s_scan, uint32_t *s_pcur, uint32_t *s_runs,
                                             uint32_t *s_misc /* >= 6 */, u64 *s_fhi, u64 *s_flo, uint32_t *s_fix, uint32_t *s_fcnt) {
     DBG_T(ts0);
+    constexpr int DS = (NT == MG_BLOCK) ? 4 : 17;        // phase-clock slots: small / big workgroup variant
     constexpr int R = SEL_SOLO_REG * SEL_ITEMS;
     constexpr uint32_t SEL_SOLO_GROUP = (uint32_t)R * NT;           // keys held in registers at a time
     const uint32_t ngrp = (M + SEL_SOLO_GROUP - 1) / SEL_SOLO_GROUP;
@@ -1172,7 +1173,7 @@ __device__ __forceinline__ void select_solo(const SelJob &job, const SelOut &out
     Pfx pfx = {0, 0, 0}, msk = {0, 0, 0};
     uint32_t bitpos = 0, nbelow = 0;                 // keys strictly below the prefix: all of them are in the top k
     constexpr uint32_t BPT = MG_SEL_BINS / NT;
-    DBG_T(ts1); DBG_ADD(4, ts0, ts1);
+    DBG_T(ts1); DBG_ADD(DS, ts0, ts1);
     for (;;) {
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < MG_SEL_BINS; i += NT) hist[i] = 0;
@@ -1211,7 +1212,7 @@ __device__ __forceinline__ void select_solo(const SelJob &job, const SelOut &out
             }
         }
         __syncthreads();
-        DBG_T(tc1); DBG_ADD(5, tc0, tc1);
+        DBG_T(tc1); DBG_ADD(DS + 1, tc0, tc1);
         // the bin where the running count of the surviving keys crosses what is still wanted
         const uint32_t krem = job.k - nbelow;
         uint32_t loc[BPT], lsum = 0;
@@ -1241,7 +1242,7 @@ __device__ __forceinline__ void select_solo(const SelJob &job, const SelOut &out
                 else { msk.ix |= 1u << sh; pfx.ix |= bit << sh; }
             }
         }
-        DBG_T(tc2); DBG_ADD(6, tc1, tc2);
+        DBG_T(tc2); DBG_ADD(DS + 2, tc1, tc2); if (NT != MG_BLOCK) DBG_CNT(22);
         if (nbelow + cum <= SEL_SMALL_CAP || ncur == 0) break;
         nbelow += below;
     }
@@ -1263,7 +1264,7 @@ __device__ __forceinline__ void select_solo(const SelJob &job, const SelOut &out
 #undef SOLO_LOAD
     if (threadIdx.x == 0) job.ctl[SEL_DONE] = 2u;            // later launches and host rounds leave the job alone
     sel_sort_emit<SEL_SMALL_CAP, NT>(job, out, s_fhi, s_flo, s_fix, s_fcnt);
-    DBG_T(tf1); DBG_ADD(7, tf0, tf1); DBG_CNT(8); DBG_MAX(9, ts0, tf1, M); DBG_MAX(10, tf0, tf1, M);
+    DBG_T(tf1); DBG_ADD(DS + 3, tf0, tf1); DBG_CNT(DS + 4); if (NT == MG_BLOCK) { DBG_MAX(9, ts0, tf1, M); DBG_MAX(10, tf0, tf1, M); } else { DBG_MAX(11, ts0, tf1, M); DBG_MAX(12, tf0, tf1, M); }
 }
 
 // mode HOST : host-driven continuation, grid (gx, njobs): workgroup count from gridDim.x, vb = blockIdx.x
@@ -1485,7 +1486,7 @@ __device__ __forceinline__ void select_job(const SelJob &job, const SelOut &sel_
             else
                 sel_final<SEL_SMALL_CAP>(job, sel_out, pass + 1, nkept, nwin_total, d_fin,
                                          (pass + 1 <= 1) ? nullptr : (newbuf ? job.cand[1] : job.cand[0]), s_pcur, ncur, s_fhi, s_flo, s_fix, s_fcnt);
-            DBG_T(ts4); DBG_ADD(7, ts3, ts4); DBG_CNT(8); DBG_MAX(9, ts0, ts4, M); DBG_MAX(10, ts3, ts4, M); DBG_MAX(11, ts1, ts2, M); DBG_MAX(12, ts0, ts1, M);
+            DBG_T(ts4); DBG_ADD(7, ts3, ts4); DBG_CNT(8); DBG_MAX(9, ts0, ts4, M); DBG_MAX(10, ts3, ts4, M);
             return;
         }
         if (done && !fused && mode != SELMODE_HOST && threadIdx.x == 0) L.fin[atomicAdd(L.nfin, 1u)] = job_index;
@@ -1550,11 +1551,6 @@ __global__ __launch_bounds__(MG_BLOCK) void k_select_first(const SelJob *jobs, c
         return;
     }
     const uint32_t want = sel_nblocks(M, SEL_MAX_WG);
-    if (mg_dbg_on && threadIdx.x == 0) {
-        atomicAdd(&mg_dbg_acc[17], 1ull); atomicAdd(&mg_dbg_acc[18], (unsigned long long)M);
-        atomicMax(&mg_dbg_acc[19], (unsigned long long)M); atomicAdd(&mg_dbg_acc[20], (unsigned long long)want);
-        if (job.skip_ones) atomicAdd(&mg_dbg_acc[21], 1ull);
-    }
     if (threadIdx.x == 0) {
         const uint32_t at = atomicAdd(&L.nitems[0], want);
         s_misc[0] = (at + want <= L.cap_items) ? at : 0xFFFFFFFFu;       // no room: the host rounds pick the job up

@@ -172,6 +172,11 @@ int mq_set_text(m_query_t *q, const char *text) {
     return 0;
 }
 
+#define M_MAX_SHARDS_MERGE 64           /* run-merge fast path of m_form_result; more shards use the full sort */
+#define FACET_FAST_CAP 256
+#define FACET_FAST_TAB_LOG 10
+#define FACET_FAST_TAB (1 << FACET_FAST_TAB_LOG)
+
 /* ------------------------------------------------------------------ comparators */
 bool m_rank_lt(const m_docrank_t *a, const m_docrank_t *b, const int *rules) {
     for (int c = 0;; c++) {
@@ -196,6 +201,55 @@ bool m_rank_lt_canonical(const m_docrank_t *a, const m_docrank_t *b, const int *
     return a->docid < b->docid;
 }
 
+/* three-way form of m_rank_lt_canonical in one walk over the rules: < 0 when a sorts first */
+static inline int rank_cmp_canonical(const m_docrank_t *a, const m_docrank_t *b, const int *rules) {
+    for (int c = 0;; c++) {
+        switch (rules[c]) {
+            case MR_TYPO:  if (a->typos != b->typos) return a->typos < b->typos ? -1 : 1; break;
+            case MR_PROX:  if (a->proximity != b->proximity) return a->proximity < b->proximity ? -1 : 1; break;
+            case MR_POS:   if (a->position != b->position) return a->position < b->position ? -1 : 1; break;
+            case MR_EXACT: if (a->exact != b->exact) return a->exact > b->exact ? -1 : 1; break;
+            case MR_COMP:  if (a->compare != b->compare) return a->compare > b->compare ? -1 : 1; break;
+            case MR_COMP_ASC: if (a->compare != b->compare) return a->compare < b->compare ? -1 : 1; break;
+            case MR_FIELD: if (a->field != b->field) return a->field < b->field ? -1 : 1; break;
+            case MR_GEO:   if (a->distance != b->distance) return a->distance < b->distance ? -1 : 1; break;
+            default:
+                if (a->shard_id != b->shard_id) return a->shard_id < b->shard_id ? -1 : 1;
+                return a->docid < b->docid ? -1 : (a->docid > b->docid);
+        }
+    }
+}
+
+/* merge sort on the canonical order that starts from the runs the caller names (run_end[r] = one past
+ * run r, each run already in canonical order: a shard's own top-2N list), so that merging S shards
+ * costs log2(S) passes; with nruns = 0 it is a plain bottom-up merge sort. */
+static void rank_merge_runs(m_docrank_t *a, size_t n, const int *rules, const size_t *run_end, int nruns) {
+    if (n < 2) return;
+    m_docrank_t stack_tmp[256];
+    size_t bounds_a[2 * M_MAX_SHARDS_MERGE + 2], bounds_b[2 * M_MAX_SHARDS_MERGE + 2];
+    m_docrank_t *tmp = n <= 256 ? stack_tmp : malloc(n * sizeof(m_docrank_t));
+    if (nruns <= 0 || nruns > 2 * M_MAX_SHARDS_MERGE) { if (tmp != stack_tmp) free(tmp); m_rank_sort_canonical(a, n, rules); return; }
+    size_t *cur = bounds_a, *nxt = bounds_b;
+    for (int r = 0; r < nruns; r++) cur[r] = run_end[r];
+    m_docrank_t *src = a, *dst = tmp;
+    while (nruns > 1) {
+        int o = 0; size_t lo = 0;
+        for (int r = 0; r < nruns; r += 2) {
+            const size_t mid = cur[r], hi = (r + 1 < nruns) ? cur[r + 1] : cur[r];
+            size_t i = lo, j = mid, k = lo;
+            while (i < mid && j < hi) dst[k++] = rank_cmp_canonical(&src[j], &src[i], rules) < 0 ? src[j++] : src[i++];
+            while (i < mid) dst[k++] = src[i++];
+            while (j < hi) dst[k++] = src[j++];
+            nxt[o++] = hi; lo = hi;
+        }
+        nruns = o;
+        m_docrank_t *t = src; src = dst; dst = t;
+        size_t *tb = cur; cur = nxt; nxt = tb;
+    }
+    if (src != a) memcpy(a, src, n * sizeof(m_docrank_t));
+    if (tmp != stack_tmp) free(tmp);
+}
+
 /* bottom-up merge sort on the canonical order */
 void m_rank_sort_canonical(m_docrank_t *a, size_t n, const int *rules) {
     if (n < 2) return;
@@ -205,7 +259,7 @@ void m_rank_sort_canonical(m_docrank_t *a, size_t n, const int *rules) {
         for (size_t lo = 0; lo < n; lo += 2 * w) {
             size_t mid = lo + w < n ? lo + w : n, hi = lo + 2 * w < n ? lo + 2 * w : n;
             size_t i = lo, j = mid, k = lo;
-            while (i < mid && j < hi) dst[k++] = m_rank_lt_canonical(&src[j], &src[i], rules) ? src[j++] : src[i++];
+            while (i < mid && j < hi) dst[k++] = rank_cmp_canonical(&src[j], &src[i], rules) < 0 ? src[j++] : src[i++];
             while (i < mid) dst[k++] = src[i++];
             while (j < hi) dst[k++] = src[j++];
         }
@@ -280,15 +334,22 @@ void m_form_result(const m_query_t *q, m_sqresult_t *sq, int num_shards, m_resul
     /* ranks: concat with shard_id stamped, then sort (query.c:343-378) */
     out->ranks = malloc((total_ranks ? total_ranks : 1) * sizeof(m_docrank_t));
     int pos = 0;
+    /* each shard's list arrives in canonical order (checked while copying): the sort is then a merge
+     * of num_shards runs; a list that is not sorted falls back to the full sort */
+    size_t run_end[M_MAX_SHARDS_MERGE];
+    int nruns = 0; bool runs_ok = num_shards <= M_MAX_SHARDS_MERGE;
     for (int i = 0; i < num_shards; i++) {
         for (int j = 0; j < sq[i].rank_count; j++) {
             out->ranks[pos] = sq[i].ranks[j];
             out->ranks[pos].shard_id = (uint8_t)i;
+            if (runs_ok && j && rank_cmp_canonical(&out->ranks[pos - 1], &out->ranks[pos], q->rank_rule) > 0) runs_ok = false;
             pos++;
         }
+        if (runs_ok && sq[i].rank_count) run_end[nruns++] = (size_t)pos;
     }
     out->total_ranks = total_ranks;
-    m_rank_sort_canonical(out->ranks, (size_t)total_ranks, q->rank_rule);
+    if (runs_ok) rank_merge_runs(out->ranks, (size_t)total_ranks, q->rank_rule, run_end, nruns);
+    else m_rank_sort_canonical(out->ranks, (size_t)total_ranks, q->rank_rule);
 
     /* aggs: merged in shard order into the query's fresh aggs (query.c:373-375) */
     out->num_aggs = q->num_aggs;
@@ -316,6 +377,45 @@ void m_form_result(const m_query_t *q, m_sqresult_t *sq, int num_shards, m_resul
         for (int i = 0; i < num_shards; i++) cap += sq[i].rcount[f];
         m_facet_count_t *fc = malloc((cap ? cap : 1) * sizeof(m_facet_count_t));
         int rcount = 0;
+        if (cap <= FACET_FAST_CAP) {
+            /* the common size (num_shards x 2N entries): find-or-append through a small open-addressing
+             * table (shards in order, so an id keeps its lowest shard), then a bounded insertion keeps the
+             * best max_facet_results by (count desc, id asc) */
+            int16_t tab[FACET_FAST_TAB];
+            memset(tab, 0xFF, sizeof(tab));
+            for (int i = 0; i < num_shards; i++)
+                for (int j = 0; j < sq[i].rcount[f]; j++) {
+                    const m_facet_count_t *e = &sq[i].fc[f][j];
+                    uint32_t h = (e->facet_id * 2654435761u) >> (32 - FACET_FAST_TAB_LOG);
+                    while (tab[h] >= 0 && fc[tab[h]].facet_id != e->facet_id) h = (h + 1) & (FACET_FAST_TAB - 1);
+                    if (tab[h] >= 0) fc[tab[h]].count += e->count;
+                    else { tab[h] = (int16_t)rcount; fc[rcount] = *e; fc[rcount].shard_id = (uint8_t)i; rcount++; }
+                }
+            const int want = q->cfg.max_facet_results < rcount ? q->cfg.max_facet_results : rcount;
+            if (want > 0 && want <= 64) {
+                m_facet_count_t best[64];
+                int nb = 0;
+                for (int k = 0; k < rcount; k++) {
+                    const m_facet_count_t e = fc[k];
+                    if (nb == want) {
+                        const m_facet_count_t *w = &best[nb - 1];
+                        if (!(e.count > w->count || (e.count == w->count && e.facet_id < w->facet_id))) continue;
+                    }
+                    int at = nb < want ? nb++ : nb - 1;
+                    while (at > 0 && (e.count > best[at - 1].count ||
+                                      (e.count == best[at - 1].count && e.facet_id < best[at - 1].facet_id))) { best[at] = best[at - 1]; at--; }
+                    best[at] = e;
+                }
+                memcpy(fc, best, (size_t)nb * sizeof(m_facet_count_t));
+                rcount = nb;
+            } else {
+                qsort(fc, (size_t)rcount, sizeof(m_facet_count_t), cmp_fc);
+                if (rcount > q->cfg.max_facet_results) rcount = q->cfg.max_facet_results;
+            }
+            out->fc[f] = fc;
+            out->fcount[f] = rcount;
+            continue;
+        }
         /* same sums as the reference's find-or-append walk, without its quadratic search:
          * order by (facet id, shard), fold equal ids into the first (= lowest shard) entry */
         for (int i = 0; i < num_shards; i++)

@@ -11,8 +11,8 @@ shards = bench.build_shards(lib, 10_000_000, list(range(8)))
 ix = Index.from_shards({}, shards, ["str"], ["num", "price"], ["flag"], ["cat", "hc"])
 eng = GpuEngine(ix, device=0)
 lib.msq_set_plan_threads(16)
-pool = [ix.query(j) for j in bench.make_queries(lib, 64)]
-B = 32
+pool = [ix.query(j) for j in bench.make_queries(lib, 256)]
+B = int(os.environ.get("PROBE_BATCH", "32"))
 prep = eng.prepare(pool[:B])
 qarr = (C.POINTER(ffi.Query) * B)(*[p.q for p in pool[:B]])
 for _ in range(5):

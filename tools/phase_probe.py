@@ -36,9 +36,10 @@ tiles = max(1, v[3]); jobs = max(1, v[8])
 print("rank whole-before-phase2 per tile us: %.2f (setup + phase1 + phase1b)" % (v[16] / max(1, v[3]) / 100))
 print("rank tiles/launch", tiles / 1, "per-tile us: setup %.2f phase1 %.2f phase2 %.2f" % (v[0] / tiles / 100, v[1] / tiles / 100, v[2] / tiles / 100))
 print("select fused jobs/launch", jobs / 1, "us per WG (all WGs incl. idle contribute to setup): setup %.2f chunks %.2f decide %.2f final %.2f" % (v[4] / jobs / 100, v[5] / jobs / 100, v[6] / jobs / 100, v[7] / jobs / 100))
-for slot, name in ((13, "ANY exit WG"), (9, "whole WG"), (10, "final"), (11, "chunks"), (12, "setup")):
+for slot, name in ((13, "ANY exit WG"), (9, "whole WG"), (10, "final"), (11, "mid whole WG"), (12, "mid final")):
     print("select max %s: %.1f us at M=%d" % (name, (v[slot] >> 32) / 100, v[slot] & 0xFFFFFFFF))
-print("wide select jobs %d (facet jobs %d), sum M %d, max M %d, workgroups asked %d" % (v[17], v[21], v[18], v[19], v[20]))
+mj = max(1, v[21])
+print("mid select jobs %d, passes %.2f per job, us per job: setup %.2f sweeps %.2f decide %.2f final %.2f" % (v[21], v[22] / mj, v[17] / mj / 100, v[18] / mj / 100, v[19] / mj / 100, v[20] / mj / 100))
 cal = (C.c_ulonglong * 3)()
 gpu.mgk_debug_clock_cal.argtypes = [C.POINTER(C.c_ulonglong)]
 gpu.mgk_debug_clock_cal(cal)
