@@ -478,7 +478,7 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
     Bump zer;          // rest of the zero region
     Bump nz;           // non-zero region
     std::vector<int> nrows(n, 0);
-    uint32_t max_nblk = 1, max_N = 1, max_pblocks = 1, max_fk = 1, max_selm = 1, max_tab = 1;
+    uint32_t max_nblk = 1, max_N = 1, max_pblocks = 1, max_fk = 1, max_selm = 1, max_tab = 1, max_fac_k = 0, max_fac_nord = 0;
 
     struct Offs {      // arena offsets per squery (zero or nonzero region relative)
         size_t rows, hist[MGPU_MAX_FIELDS], touched[MGPU_MAX_FIELDS], ntouched[MGPU_MAX_FIELDS], andor, ovfcnt, docmap, blk, hits, khi, klo, ovfl, aggpart;
@@ -686,6 +686,7 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
                 if (fk > MG_SEL_FINAL) return fail(MGPU_E_LIMIT, "2*maxFacetResults (capped by distinct values) above 2048");
                 int j = h.nfac++;
                 h.fac_field[j] = f; h.fac_k[j] = fk;
+                max_fac_k = std::max(max_fac_k, fk); max_fac_nord = std::max(max_fac_nord, sd.fa_nord[f]);
                 h.fac_hi[j] = res.take((size_t)fk * 8); h.fac_lo[j] = res.take((size_t)fk * 8); h.fac_pl[j] = res.take((size_t)fk * 4);
             }
         }
@@ -817,6 +818,9 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
             items.push_back(it);
         }
     }
+    // facet keys: when every facet list of the batch fits the one-workgroup selections, those derive
+    // the keys from the touched bins themselves and k_fkeys is not launched
+    const bool fuse_fk = max_fac_nord <= MG_SEL_MID_KEYS && max_fac_k <= MG_SEL_SOLO_K && !getenv("MGPU_NO_FUSED_FKEYS");
     seljobs.resize(seloff.size()); selouts.resize(seloff.size());
     for (size_t j = 0; j < seloff.size(); j++) {
         const SelOff &so = seloff[j]; const JobFix &jf = jobfix[j];
@@ -844,7 +848,8 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
             FkJob fj; fj.hist = q.hist[f]; fj.ord2id = q.sh.fa_ord2id[f]; fj.touched = q.touched[f]; fj.ntouched = q.ntouched[f];
             fj.key_hi = (u64 *)q.fkey_hi[f]; fj.key_lo = (u64 *)q.fkey_lo[f];
             fj.andor = (u64 *)(Z + so.andor);
-            fkjobs.push_back(fj);
+            if (fuse_fk) { sj.gen_touched = fj.touched; sj.gen_hist = fj.hist; sj.gen_ord2id = fj.ord2id; }
+            else fkjobs.push_back(fj);
         }
     }
     for (int i = 0; i < n; i++) {

@@ -1056,7 +1056,9 @@ __device__ __forceinline__ void sel_sort_emit(const SelJob &job, const SelOut &o
     const uint32_t kk = job.k < n ? job.k : n;
     for (uint32_t i = threadIdx.x; i < kk; i += NT) {
         if (job.skip_ones && s_hi[i] == ~0ull) continue;
-        out.out_hi[i] = s_hi[i]; out.out_lo[i] = s_lo[i];
+        // derived facet keys carry the bin ordinal (same order as the facet id: ordinals are ranks of
+        // the sorted ids); the id itself is looked up for the k winners only
+        out.out_hi[i] = s_hi[i]; out.out_lo[i] = job.gen_touched ? (u64)job.gen_ord2id[s_lo[i]] : s_lo[i];
         out.out_pl[i] = out.payload ? out.payload[s_ix[i]] : s_ix[i];
         atomicAdd(&s_cnt[1], 1u);
     }
@@ -1128,7 +1130,7 @@ __device__ __forceinline__ void sel_final(const SelJob &job, const SelOut &out, 
 #define SEL_WIDE_LAUNCHES 3
 struct SelLists { uint2 *items[SEL_WIDE_LAUNCHES + 1]; uint32_t *nitems; uint32_t *fin; uint32_t *nfin; uint32_t cap_items;
                   uint32_t *mid; uint32_t *nmid; };
-enum { SELMODE_HOST = 0, SELMODE_FIRST = 1, SELMODE_ITEMS = 2 };
+enum { SELMODE_HOST = 0, SELMODE_ITEMS = 2 };
 
 // The digit's bit positions folded into runs of adjacent bits inside one 32-bit word of the key
 // (word 0..3 = hi.hi, hi.lo, lo.hi, lo.lo, 4 = idx), MSB first: (word << 16 | low bit << 8 | length).
@@ -1152,13 +1154,14 @@ __device__ __forceinline__ int digit_runs(const uint32_t *pos, int n, uint32_t *
 // chosen so far (pfx under mask msk, both over the varying bits consumed); the keys at or below the
 // last prefix are the final set.  Same decisions as the compacting passes, no lists, no fences.
 #define SEL_SOLO_REG 1
-#define SEL_MID_KEYS 131072u                            // longest fresh list that one 1024-thread workgroup selects (k_select_mid)
+#define SEL_MID_KEYS MG_SEL_MID_KEYS
 #define SEL_MID_BLOCK 1024
 struct Pfx { u64 hi, lo; uint32_t ix; };
 template <int NT>
 __device__ __forceinline__ void select_solo(const SelJob &job, const SelOut &out, uint32_t M, u64 mhi, u64 mlo, uint32_t midx,
                                             uint32_t *hist, uint32_t *s_scan, uint32_t *s_pcur, uint32_t *s_runs,
-                                            uint32_t *s_misc /* >= 6 */, u64 *s_fhi, u64 *s_flo, uint32_t *s_fix, uint32_t *s_fcnt) {
+                                            uint32_t *s_misc /* >= 6 */, u64 *s_fhi, u64 *s_flo, uint32_t *s_fix, uint32_t *s_fcnt,
+                                            u64 *s_red /* >= 4 * NT / 64 */) {
     DBG_T(ts0);
     constexpr int DS = (NT == MG_BLOCK) ? 4 : 17;        // phase-clock slots: small / big workgroup variant
     constexpr int R = SEL_SOLO_REG * SEL_ITEMS;
@@ -1169,7 +1172,36 @@ __device__ __forceinline__ void select_solo(const SelJob &job, const SelOut &out
 #define SOLO_LOAD(g) do { _Pragma("unroll") for (int u = 0; u < R; u++) { \
         const uint32_t i = (g) * SEL_SOLO_GROUP + u * NT + threadIdx.x; \
         rhi[u] = (i < M) ? job.key_hi[i] : 0; rlo[u] = (i < M) ? job.key_lo[i] : 0; } } while (0)
-    if (reg) SOLO_LOAD(0);
+    // facet keys derived here from the touched bins: (0xFFFFFFFF - count, bin ordinal), loads batched R deep
+#define SOLO_GEN(g) do { uint32_t bins[R]; _Pragma("unroll") for (int u = 0; u < R; u++) { \
+        const uint32_t i = (g) * SEL_SOLO_GROUP + u * NT + threadIdx.x; bins[u] = (i < M) ? job.gen_touched[i] : 0xFFFFFFFFu; } \
+        _Pragma("unroll") for (int u = 0; u < R; u++) { const bool v = bins[u] != 0xFFFFFFFFu; \
+        rhi[u] = v ? (u64)(0xFFFFFFFFu - job.gen_hist[bins[u]]) : 0; rlo[u] = v ? (u64)bins[u] : 0; } } while (0)
+    if (job.gen_touched) {
+        // the varying bits of these keys are not known yet: OR / AND them over the list first.  A list
+        // beyond the registers is written to key_hi/key_lo on the way, and read back from there after.
+        u64 a = 0, b = 0, na = 0, nb = 0;
+        for (uint32_t g = 0; g < ngrp; g++) {
+            SOLO_GEN(g);
+#pragma unroll
+            for (int u = 0; u < R; u++) {
+                const uint32_t i = g * SEL_SOLO_GROUP + u * NT + threadIdx.x;
+                if (i < M) {
+                    a |= rhi[u]; b |= rlo[u]; na |= ~rhi[u]; nb |= ~rlo[u];
+                    if (!reg) { ((u64 *)job.key_hi)[i] = rhi[u]; ((u64 *)job.key_lo)[i] = rlo[u]; }
+                }
+            }
+        }
+        a = wave_or64(a); b = wave_or64(b); na = wave_or64(na); nb = wave_or64(nb);
+        if ((threadIdx.x & 63) == 0) { u64 *r = s_red + 4 * (threadIdx.x >> 6); r[0] = a; r[1] = b; r[2] = na; r[3] = nb; }
+        if (!reg) __threadfence();
+        __syncthreads();
+        a = b = na = nb = 0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; w++) { a |= s_red[4 * w]; b |= s_red[4 * w + 1]; na |= s_red[4 * w + 2]; nb |= s_red[4 * w + 3]; }
+        mhi = a & na; mlo = b & nb;
+    } else if (reg) SOLO_LOAD(0);
+#undef SOLO_GEN
     Pfx pfx = {0, 0, 0}, msk = {0, 0, 0};
     uint32_t bitpos = 0, nbelow = 0;                 // keys strictly below the prefix: all of them are in the top k
     constexpr uint32_t BPT = MG_SEL_BINS / NT;
@@ -1268,11 +1300,9 @@ __device__ __forceinline__ void select_solo(const SelJob &job, const SelOut &out
 }
 
 // mode HOST : host-driven continuation, grid (gx, njobs): workgroup count from gridDim.x, vb = blockIdx.x
-// mode FIRST: first launch, one workgroup per job (vb = 0); too-long lists are handed to items[0]
 // mode ITEMS: wide launch `slot` over items[slot]; this workgroup is number vb of ctl[SEL_NB]
 __device__ __forceinline__ void select_job(const SelJob &job, const SelOut &sel_out, int mode, uint32_t job_index,
                                            uint32_t vb, const SelLists &L, int slot) {
-    const int solo_only = mode == SELMODE_FIRST;
     uint32_t *ctl = job.ctl;
     const uint32_t M = *job.m_ptr;
     __shared__ u64 s_fhi[SEL_SMALL_CAP], s_flo[SEL_SMALL_CAP];
@@ -1280,10 +1310,8 @@ __device__ __forceinline__ void select_job(const SelJob &job, const SelOut &sel_
     DBG_T(ts0);
     DbgScope dbg_scope(13); dbg_scope.tag = M;
     // until a final sort has run the host must see "not finished"
-    // (in the first launch the control words are known to be zero: the arena was just cleared)
     if (vb == 0 && threadIdx.x == 0 &&
-        (mode == SELMODE_FIRST || __hip_atomic_load(&ctl[SEL_DONE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 2u))
-        *job.out_n = 0xFFFFFFFFu;
+        __hip_atomic_load(&ctl[SEL_DONE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 2u) *job.out_n = 0xFFFFFFFFu;
     __shared__ uint32_t hist[MG_SEL_BINS];
     __shared__ uint32_t s_ctl[SEL_WORDS];
     __shared__ uint32_t s_scan[8];
@@ -1298,9 +1326,7 @@ __device__ __forceinline__ void select_job(const SelJob &job, const SelOut &sel_
 
     for (;;) {
         __syncthreads();
-        if (threadIdx.x < SEL_WORDS)
-            s_ctl[threadIdx.x] = (mode == SELMODE_FIRST && !continuing) ? 0u
-                               : __hip_atomic_load(&ctl[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x < SEL_WORDS) s_ctl[threadIdx.x] = __hip_atomic_load(&ctl[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         if (s_ctl[SEL_DONE]) return;
         const uint32_t pass = s_ctl[SEL_PASS];
@@ -1315,22 +1341,7 @@ __device__ __forceinline__ void select_job(const SelJob &job, const SelOut &sel_
             if (small) sel_final<SEL_SMALL_CAP>(job, sel_out, 0, M, 0, 0, nullptr, s_pcur, 0, s_fhi, s_flo, s_fix, s_fcnt);
             return;
         }
-        // first launch of a batch: one workgroup per job, lists beyond a lone workgroup's reach are
-        // left for the continuation rounds (which bring a wider grid)
-        if (solo_only && nin > SEL_SOLO_CHUNKS * SEL_CHUNK) {
-            // ask for exactly the workgroups this list needs in the first wide launch
-            const uint32_t want = sel_nblocks(nin, SEL_MAX_WG);
-            if (threadIdx.x == 0) {
-                const uint32_t at = atomicAdd(&L.nitems[0], want);
-                s_at = (at + want <= L.cap_items) ? at : 0xFFFFFFFFu;       // no room: the host rounds pick the job up
-                ctl[SEL_NB] = want;
-            }
-            __syncthreads();
-            if (s_at != 0xFFFFFFFFu && threadIdx.x < want) L.items[0][s_at + threadIdx.x] = make_uint2(job_index, threadIdx.x);
-            return;
-        }
-        const uint32_t nb = continuing ? 1u : mode == SELMODE_ITEMS ? s_ctl[SEL_NB] : mode == SELMODE_FIRST ? 1u
-                                                                                       : sel_nblocks(nin, gridDim.x);
+        const uint32_t nb = continuing ? 1u : mode == SELMODE_ITEMS ? s_ctl[SEL_NB] : sel_nblocks(nin, gridDim.x);
         if (!continuing && vbid >= nb) return;
         const bool solo = nb == 1;
 
@@ -1508,7 +1519,7 @@ __device__ __forceinline__ void select_job(const SelJob &job, const SelOut &sel_
     }
 }
 
-// mode FIRST / HOST: grid (gx, njobs)
+// host-driven continuation rounds: grid (gx, njobs)
 __global__ __launch_bounds__(MG_BLOCK) void k_select_pass(const SelJob *jobs, const SelOut *outs, int mode, SelLists L) {
     const SelJob job = jobs[blockIdx.y];
     select_job(job, outs[blockIdx.y], mode, blockIdx.y, blockIdx.x, L, 0);
@@ -1526,10 +1537,28 @@ __global__ __launch_bounds__(MG_BLOCK) void k_select_first(const SelJob *jobs, c
     __shared__ uint32_t s_fix[SEL_SMALL_CAP], s_fcnt[2];
     __shared__ uint32_t hist[MG_SEL_BINS];
     __shared__ uint32_t s_scan[8], s_pcur[MG_SEL_DIGIT], s_runs[MG_SEL_DIGIT], s_misc[8];
+    __shared__ u64 s_red[4 * MG_BLOCK / 64];
     DbgScope dbg_scope(13); dbg_scope.tag = M;
     if (M <= SEL_SMALL_CAP) {
-        if (threadIdx.x == 0) { job.ctl[SEL_NIN] = M; job.ctl[SEL_KREM] = job.k; job.ctl[SEL_NFIN] = M; job.ctl[SEL_DONE] = 2u; }
-        sel_final<SEL_SMALL_CAP>(job, out, 0, M, 0, 0, nullptr, s_pcur, 0, s_fhi, s_flo, s_fix, s_fcnt);
+        // short list: straight into the sort
+        if (threadIdx.x == 0) { job.ctl[SEL_NIN] = M; job.ctl[SEL_KREM] = job.k; job.ctl[SEL_NFIN] = M; job.ctl[SEL_DONE] = 2u;
+                                s_fcnt[0] = M; s_fcnt[1] = 0; }
+        uint32_t bins[SEL_SMALL_CAP / MG_BLOCK];
+#pragma unroll
+        for (int u = 0; u < SEL_SMALL_CAP / MG_BLOCK; u++) {
+            const uint32_t i = u * MG_BLOCK + threadIdx.x;
+            bins[u] = (job.gen_touched && i < M) ? job.gen_touched[i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < SEL_SMALL_CAP / MG_BLOCK; u++) {
+            const uint32_t i = u * MG_BLOCK + threadIdx.x;
+            if (i < M) {
+                s_fhi[i] = job.gen_touched ? (u64)(0xFFFFFFFFu - job.gen_hist[bins[u]]) : job.key_hi[i];
+                s_flo[i] = job.gen_touched ? (u64)bins[u] : job.key_lo[i];
+                s_fix[i] = i;
+            }
+        }
+        sel_sort_emit<SEL_SMALL_CAP>(job, out, s_fhi, s_flo, s_fix, s_fcnt);
         return;
     }
     if (threadIdx.x == 0) *job.out_n = 0xFFFFFFFFu;          // until a final sort has run the host must see "not finished"
@@ -1540,13 +1569,13 @@ __global__ __launch_bounds__(MG_BLOCK) void k_select_first(const SelJob *jobs, c
         }
         return;
     }
-    if (M <= SEL_SOLO_CHUNKS * SEL_CHUNK && job.k <= SEL_SMALL_CAP / 2) {
+    if (M <= SEL_SOLO_CHUNKS * SEL_CHUNK && job.k <= MG_SEL_SOLO_K) {
         u64 mhi, mlo; uint32_t midx;
         job_masks(job, M, mhi, mlo, midx);
-        select_solo<MG_BLOCK>(job, out, M, mhi, mlo, midx, hist, s_scan, s_pcur, s_runs, s_misc, s_fhi, s_flo, s_fix, s_fcnt);
+        select_solo<MG_BLOCK>(job, out, M, mhi, mlo, midx, hist, s_scan, s_pcur, s_runs, s_misc, s_fhi, s_flo, s_fix, s_fcnt, s_red);
         return;
     }
-    if (M <= SEL_MID_KEYS && job.k <= SEL_SMALL_CAP / 2) {    // same selection by a 1024-thread workgroup of k_select_mid
+    if (M <= SEL_MID_KEYS && job.k <= MG_SEL_SOLO_K) {    // same selection by a 1024-thread workgroup of k_select_mid
         if (threadIdx.x == 0) L.mid[atomicAdd(L.nmid, 1u)] = ji;
         return;
     }
@@ -1566,6 +1595,7 @@ __global__ __launch_bounds__(SEL_MID_BLOCK) void k_select_mid(const SelJob *jobs
     __shared__ uint32_t s_fix[SEL_SMALL_CAP], s_fcnt[2];
     __shared__ uint32_t hist[MG_SEL_BINS];
     __shared__ uint32_t s_scan[SEL_MID_BLOCK / 64], s_pcur[MG_SEL_DIGIT], s_runs[MG_SEL_DIGIT], s_misc[8];
+    __shared__ u64 s_red[4 * SEL_MID_BLOCK / 64];
     const uint32_t n = *L.nmid;
     for (uint32_t w = blockIdx.x; w < n; w += gridDim.x) {
         const uint32_t ji = L.mid[w];
@@ -1573,7 +1603,7 @@ __global__ __launch_bounds__(SEL_MID_BLOCK) void k_select_mid(const SelJob *jobs
         const uint32_t M = *job.m_ptr;
         u64 mhi, mlo; uint32_t midx;
         job_masks(job, M, mhi, mlo, midx);
-        select_solo<SEL_MID_BLOCK>(job, outs[ji], M, mhi, mlo, midx, hist, s_scan, s_pcur, s_runs, s_misc, s_fhi, s_flo, s_fix, s_fcnt);
+        select_solo<SEL_MID_BLOCK>(job, outs[ji], M, mhi, mlo, midx, hist, s_scan, s_pcur, s_runs, s_misc, s_fhi, s_flo, s_fix, s_fcnt, s_red);
         __syncthreads();
     }
 }

@@ -66,7 +66,13 @@ struct SelJob {                      // one top-k selection (rank keys of a sque
     uint32_t *out_n;                 // number selected = min(k, m)
     const uint64_t *mask;            // [2] varying bits (or ^ and): hi, lo ; NULL = all bits vary
     uint32_t skip_ones;              // facet jobs: never select keys with key_hi == ~0 (zero counts)
+    // facet jobs whose keys the select stage derives itself (no k_fkeys launch): key i is
+    // (0xFFFFFFFF - gen_hist[b], b) with b = gen_touched[i], emitted as gen_ord2id[b]; key_hi/key_lo are then scratch
+    // the selecting workgroup may fill; NULL = the keys are already in key_hi/key_lo
+    const uint32_t *gen_touched, *gen_hist, *gen_ord2id;
 };
+#define MG_SEL_MID_KEYS 131072u      // longest fresh list one 1024-thread workgroup selects (k_select_mid)
+#define MG_SEL_SOLO_K 256u           // largest k of the one-workgroup selections
 // ctl words
 enum { SEL_NCAND, SEL_KREM, SEL_NWIN, SEL_DONE, SEL_TICKET, SEL_NEXT, SEL_BITPOS, SEL_PASS, SEL_WORDS = 16 };
 

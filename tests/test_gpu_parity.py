@@ -68,6 +68,27 @@ def test_datagen_queries_gpu(dg):
         compare_results(g, orc_py.search(ix, pq, flags=3), ctx=pq.jq)
 
 
+def test_facet_keys_by_separate_kernel(dg, monkeypatch):
+    """facet selection keys come from k_fkeys instead of the select kernels themselves (the path a
+    batch takes when a facet field or maxFacetResults is too large for the one-workgroup selections)"""
+    ix, eng = dg
+    monkeypatch.setenv("MGPU_NO_FUSED_FKEYS", "1")
+    pqs = [ix.query(dict(jq, fullScan=True)) for jq in DG_QUERIES]
+    got = eng.search(pqs, capture=3)
+    for pq, g in zip(pqs, got):
+        compare_results(g, orc_py.search(ix, pq, flags=3), ctx=pq.jq)
+
+
+def test_many_facet_results_need_the_big_final_sort(dg):
+    """2 * maxFacetResults above the one-workgroup selection's k: keys by k_fkeys, wide passes + big sort"""
+    ix, eng = dg
+    pqs = [ix.query({"q": "", "maxFacetResults": 300, "fullScan": True}),
+           ix.query({"q": "aaaaaaa", "maxFacetResults": 200, "fullScan": True})]
+    got = eng.search(pqs, capture=3)
+    for pq, g in zip(pqs, got):
+        compare_results(g, orc_py.search(ix, pq, flags=3), ctx=pq.jq)
+
+
 def test_single_query_equals_batched(dg):
     ix, eng = dg
     pq = ix.query({"q": "aaaaaaa bbbbbbb", "rankBy": {"num": "desc"}, "fullScan": True})
