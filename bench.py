@@ -181,6 +181,9 @@ def main():
 
     def run_steps(first, count):
         """`count` steps with up to F batches in flight (one host thread and one context each)"""
+        if world == 1:
+            # one GPU: the whole loop is native (host threads, contexts, execute + merge: mplan.c)
+            return eng.run_pipeline(prepared, first, count, F)
         gather_turn[0] = 0
         hits = [0] * F
         err = []

@@ -57,6 +57,7 @@ struct mgpu_shard {
     std::vector<int32_t> post_dense;    // per pid
     std::vector<uint64_t> post_off;     // sparse CSR offsets (per pid)
     std::vector<uint32_t> post_card;    // docs per posting (bounds the hit count of a plan)
+    std::vector<uint32_t> post_winbase; // per pid: base into post_win, or ~0 (dense, empty or short posting)
     uint64_t np_n[MGPU_MAX_FIELDS];
     double avg_dw;                      // mean docword entries per doc
     double avg_fv[MGPU_MAX_FIELDS];     // mean facet values per doc
@@ -124,6 +125,30 @@ extern "C" int mgpu_shard_create(int device, const mgpu_shard_desc_t *d, mgpu_sh
             else sparse_doc.insert(sparse_doc.end(), d->post_doc + d->post_off[p], d->post_doc + d->post_off[p + 1]);
         }
         s->post_off[d->num_postings] = sparse_doc.size();
+        if (sparse_doc.size() >= 0xFFFFFFFFull) { delete s; return fail(MGPU_E_LIMIT, "more than 2^32 sparse posting entries in one shard"); }
+        for (uint32_t doc : sparse_doc) if (doc >= N) { delete s; return fail(MGPU_E_ARG, "posting docid beyond max_docid"); }
+        // window index of the long sparse postings (see ShardDev::post_win)
+        std::vector<uint32_t> post_win;
+        s->post_winbase.assign(d->num_postings, 0xFFFFFFFFu);
+        {
+            const uint32_t nwin = (sd.W + MG_FORMULA_WORDS - 1) / MG_FORMULA_WORDS;
+            for (uint32_t p = 0; p < d->num_postings; p++) {
+                if (s->post_dense[p] >= 0) continue;
+                const uint64_t b = s->post_off[p], n = s->post_off[p + 1] - b;
+                if (n <= MG_SHORT_POSTING) continue;
+                if (post_win.size() + nwin + 1 >= 0xFFFFFFFFull) { delete s; return fail(MGPU_E_LIMIT, "posting window index too large"); }
+                s->post_winbase[p] = (uint32_t)post_win.size();
+                uint64_t at = 0;
+                for (uint32_t j = 0; j <= nwin; j++) {
+                    const uint64_t lim = (uint64_t)j * 64 * MG_FORMULA_WORDS;
+                    while (at < n && sparse_doc[b + at] < lim) {
+                        if (at && sparse_doc[b + at] < sparse_doc[b + at - 1]) { delete s; return fail(MGPU_E_ARG, "posting docids not ascending"); }
+                        at++;
+                    }
+                    post_win.push_back(j == nwin ? (uint32_t)n : (uint32_t)at);
+                }
+            }
+        }
         std::vector<u64> rows((size_t)dense_pids.size() * sd.Wp, 0);
         for (size_t r = 0; r < dense_pids.size(); r++) {
             uint32_t p = dense_pids[r];
@@ -137,7 +162,8 @@ extern "C" int mgpu_shard_create(int device, const mgpu_shard_desc_t *d, mgpu_sh
         s->n_dense = (uint32_t)dense_pids.size();
         const u64 *p_rows; const int32_t *p_pd; const u64 *p_off; const uint32_t *p_doc;
         if ((rc = upload(s, rows, &p_rows)) || (rc = upload(s, s->post_dense, &p_pd)) ||
-            (rc = upload(s, s->post_off, (const uint64_t **)&p_off)) || (rc = upload(s, sparse_doc, &p_doc))) {
+            (rc = upload(s, s->post_off, (const uint64_t **)&p_off)) || (rc = upload(s, sparse_doc, &p_doc)) ||
+            (rc = upload(s, post_win, &sd.post_win))) {
             mgpu_shard_destroy(s); return rc;
         }
         sd.dense = (const uint64_t *)p_rows; sd.post_dense = p_pd; sd.post_off = (const uint64_t *)p_off; sd.post_doc = p_doc;
@@ -391,6 +417,7 @@ struct SqHost {                          // host bookkeeping for one squery of t
     KeyField kf[8]; int nkf;
     uint64_t formula_rows;               // rows read by the formula kernel
     uint64_t scatter_docs;
+    uint64_t sparse_docs;                // sparse posting entries of the terms (read once per squery by k_formula)
 };
 
 static int build_key_layout(const mgpu_plan_t &p, KeyField *kf, int *nkf) {
@@ -503,7 +530,7 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
         q.empty = (p.has_filter && p.filter_null) ? 1 : 0;
         q.nblk = (sd.W + MG_WORDS_PER_BLOCK - 1) / MG_WORDS_PER_BLOCK;
         max_nblk = std::max(max_nblk, q.nblk);
-        h.formula_rows = 1; h.scatter_docs = 0;
+        h.formula_rows = 1; h.scatter_docs = 0; h.sparse_docs = 0;
 
         auto use_posting = [&](uint32_t pid, int *row_io, std::vector<uint32_t> *dense_list) -> int {
             // returns 0 and either appends a dense row index or schedules a scatter into *row_io
@@ -518,6 +545,21 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
             return MGPU_OK;
         };
 
+        // a term's sparse postings are not expanded into rows: k_formula ORs the part of each list that
+        // falls into a workgroup's window straight into an LDS tile (list table below)
+        std::vector<uint32_t> sl;
+        auto use_term_posting = [&](uint32_t pid, int t, std::vector<uint32_t> *dense_list) -> int {
+            if (pid >= sd.num_postings) return fail(MGPU_E_ARG, "posting id out of range");
+            int32_t di = sh->post_dense[pid];
+            if (di >= 0) { dense_list->push_back((uint32_t)di); return MGPU_OK; }
+            uint64_t cnt = sh->post_off[pid + 1] - sh->post_off[pid];
+            if (!cnt) return MGPU_OK;
+            sl.push_back((uint32_t)t); sl.push_back((uint32_t)sh->post_off[pid]); sl.push_back((uint32_t)cnt);
+            sl.push_back(sh->post_winbase[pid]);
+            h.sparse_docs += cnt;
+            return MGPU_OK;
+        };
+
         // terms (num_terms == 0 -> every used docid, shard.c:51-53)
         int nt = p.num_terms;
         uint64_t tcard[MGPU_MAX_TERMS + 1] = {0};        // |term t| <= sum of its postings' sizes
@@ -527,18 +569,21 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
             blob.push_back((uint32_t)sh->post_dense[0]);
             q.term_dense_off[1] = (uint32_t)blob.size();
             q.term_row[0] = -1;
+            q.term_sl[0] = q.term_sl[1] = 0;
             h.formula_rows += 1;
         } else {
             q.num_terms = nt;
             for (int t = 0; t < nt; t++) {
                 std::vector<uint32_t> dl;
-                int row = -1;
+                const int row = -1;
                 uint64_t tc = 0;
+                q.term_sl[t] = (uint32_t)(sl.size() / 4);
                 for (uint32_t j = 0; j < p.term_npost[t]; j++) {
-                    int rc = use_posting(p.term_post[t][j], &row, &dl);
+                    int rc = use_term_posting(p.term_post[t][j], t, &dl);
                     if (rc) return rc;
                     tc += sh->post_card[p.term_post[t][j]];
                 }
+                q.term_sl[t + 1] = (uint32_t)(sl.size() / 4);
                 tcard[t] = std::min<uint64_t>(tc, sd.N);
                 std::sort(dl.begin(), dl.end());
                 dl.erase(std::unique(dl.begin(), dl.end()), dl.end());
@@ -611,16 +656,23 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
         // flattened plan for k_formula (staged into LDS by every workgroup)
         {
             std::vector<uint32_t> pl;
-            for (int t = 0; t < q.num_terms; t++) {
-                const uint32_t a0 = q.term_dense_off[t], a1 = q.term_dense_off[t + 1];
-                pl.push_back((a1 - a0) + (q.term_row[t] >= 0 ? 1u : 0u));
-                if (q.term_row[t] >= 0) pl.push_back((uint32_t)~q.term_row[t]);
-                for (uint32_t x = a0; x < a1; x++) pl.push_back(blob[x]);
+            uint32_t at = 0;
+            for (int t = 0; t <= q.num_terms; t++) {
+                pl.push_back(at);
+                if (t < q.num_terms) at += q.term_dense_off[t + 1] - q.term_dense_off[t];
             }
+            for (int t = 0; t < q.num_terms; t++)
+                for (uint32_t x = q.term_dense_off[t]; x < q.term_dense_off[t + 1]; x++) {
+                    if (blob[x] >= (1u << 27)) return fail(MGPU_E_LIMIT, "more than 2^27 dense rows");
+                    pl.push_back(blob[x] | ((uint32_t)t << 27));
+                }
             q.plan_fops = (uint32_t)pl.size();
             for (int j = 0; j < q.num_fops; j++) { pl.push_back(blob[q.fops_off + 2 * j]); pl.push_back(blob[q.fops_off + 2 * j + 1]); }
             q.plan_off = (uint32_t)blob.size(); q.plan_len = (uint32_t)pl.size();
             blob.insert(blob.end(), pl.begin(), pl.end());
+            while (blob.size() & 3) blob.push_back(0);       // the list table is read as uint4
+            q.sl_off = (uint32_t)blob.size();
+            blob.insert(blob.end(), sl.begin(), sl.end());
         }
         // wid table
         {
@@ -751,7 +803,7 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
     const uint32_t sel_cap_items = (uint32_t)sel_items;
     const size_t off_items = nz.take((size_t)sel_cap_items * 4 * sizeof(uint2));
     // scratch rows (zero region), now that row counts are known
-    for (int i = 0; i < n; i++) offs[i].rows = zer.take((size_t)std::max(nrows[i], 1) * sqd[i].sh.Wp * 8);
+    for (int i = 0; i < n; i++) offs[i].rows = zer.take((size_t)nrows[i] * sqd[i].sh.Wp * 8);      // filter operands only
 
     // scatter work items
     std::vector<ScatterItem> items;
@@ -1002,7 +1054,7 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
         // algorithmic bytes (DESIGN.md byte model)
         const uint64_t B = (uint64_t)q.sh.W * 8;
         c->stage_bytes[1] += h.scatter_docs * 4;
-        c->stage_bytes[2] += h.formula_rows * B + B + 4 * M;
+        c->stage_bytes[2] += h.formula_rows * B + h.sparse_docs * 4 + B + 4 * M;
         if (h.k) c->stage_bytes[3] += M * (uint64_t)(4 + 16 + 8.0 * sh->avg_dw + (p.rank_by >= 0 ? 8 : 0) + 16);
         {
             double per = 0;

@@ -24,7 +24,7 @@ __device__ __forceinline__ uint32_t wave_sum32(uint32_t v) {
 }
 // ---- optional phase clocks (mgpu_debug_phases): cycles summed per phase over the active workgroups
 __device__ int mg_dbg_on = 0;
-__device__ unsigned long long mg_dbg_acc[24];
+__device__ unsigned long long mg_dbg_acc[32];
 #define DBG_T(var) const long long var = mg_dbg_on ? (long long)wall_clock64() : 0
 #define DBG_ADD(slot, a, b) do { if (mg_dbg_on && threadIdx.x == 0) atomicAdd(&mg_dbg_acc[slot], (unsigned long long)((b) - (a))); } while (0)
 #define DBG_MAX(slot, a, b, tag) do { if (mg_dbg_on && threadIdx.x == 0) atomicMax(&mg_dbg_acc[slot], ((unsigned long long)((b) - (a)) << 32) | (unsigned long long)(tag)); } while (0)
@@ -91,21 +91,26 @@ __global__ __launch_bounds__(MG_BLOCK) void k_scatter(const ScatterItem *items, 
 // ------------------------------------------------------------------ formula + filter + popcount
 // get_matching_docids (squery.c:212-277) fused with squery_apply_filters (squery.c:377-395,
 // filter_apply.c:207-227) and bmap_cardinality (bmap.c:362-368).
-// A workgroup owns MG_FORMULA_WORDS consecutive u64 words of the squery's rows: it stages the
-// flattened plan (row list per term + filter program) into LDS once, then every lane streams
-// 2 x 16 bytes of each row (four words in flight per row step) and combines them in registers.
-#define MG_FORMULA_WORDS 1024
+// A workgroup owns one window = MG_FORMULA_WORDS consecutive u64 words (32768 docids) of the squery's
+// rows; lane t owns words 2t, 2t+1 of it.  Every term gets a tile of the window in LDS:
+//   dense postings: the lane ORs its 16 bytes of each dense row of the term into its words of the
+//     tile (one flat list of {row, term} entries, loads batched four deep, no synchronisation);
+//   sparse postings never become rows in memory: the list table gives {term, first element, length,
+//     window index}, one lane per list looks up its [start, end) for this window (post_win; short
+//     lists are taken whole and filtered by docid), a block scan turns the lengths into one flat
+//     element range and the lanes stride over it with LDS atomic ORs -- every element load of the
+//     workgroup is in flight at once.
+// The match formula and the filter program then run on the tiles in registers.
 #define MG_PLAN_LDS 1024
-struct W4 { u64 a, b, c, d; };
-__device__ __forceinline__ W4 w4_or(W4 x, W4 y) { return {x.a | y.a, x.b | y.b, x.c | y.c, x.d | y.d}; }
-__device__ __forceinline__ W4 w4_and(W4 x, W4 y) { return {x.a & y.a, x.b & y.b, x.c & y.c, x.d & y.d}; }
-__device__ __forceinline__ W4 w4_andnot(W4 x, W4 y) { return {x.a & ~y.a, x.b & ~y.b, x.c & ~y.c, x.d & ~y.d}; }
-__device__ __forceinline__ W4 w4_load(const u64 *row, uint32_t w0, uint32_t w1, bool in0, bool in1) {
+#define MG_TILE_TERMS 6              // term tiles held in LDS at once (24 KiB): every term of a query of <= 3 words
+struct W2 { u64 a, b; };
+__device__ __forceinline__ W2 w2_or(W2 x, W2 y) { return {x.a | y.a, x.b | y.b}; }
+__device__ __forceinline__ W2 w2_and(W2 x, W2 y) { return {x.a & y.a, x.b & y.b}; }
+__device__ __forceinline__ W2 w2_andnot(W2 x, W2 y) { return {x.a & ~y.a, x.b & ~y.b}; }
+__device__ __forceinline__ W2 w2_load(const u64 *row, uint32_t w0, bool in0) {
     // rows are padded to a multiple of 32 words (Wp), so a pair of words never straddles the end
-    const ulonglong2 z = make_ulonglong2(0ull, 0ull);
-    const ulonglong2 x = in0 ? *(const ulonglong2 *)(row + w0) : z;
-    const ulonglong2 y = in1 ? *(const ulonglong2 *)(row + w1) : z;
-    return {x.x, x.y, y.x, y.y};
+    const ulonglong2 x = in0 ? *(const ulonglong2 *)(row + w0) : make_ulonglong2(0ull, 0ull);
+    return {x.x, x.y};
 }
 
 __global__ __launch_bounds__(MG_BLOCK) void k_formula(const SqDev *sqs, const uint32_t *blob) {
@@ -118,76 +123,149 @@ __global__ __launch_bounds__(MG_BLOCK) void k_formula(const SqDev *sqs, const ui
     const uint32_t plan_off = sp->plan_off, plan_len = sp->plan_len, plan_fops = sp->plan_fops;
     const u64 *dense = (const u64 *)sp->sh.dense;
     const u64 *rows = (const u64 *)sp->rows;
+    const uint32_t *post_doc = sp->sh.post_doc, *post_win = sp->sh.post_win;
+    const uint4 *sl = (const uint4 *)(blob + sp->sl_off);
     u64 *docid_map = (u64 *)sp->docid_map;
     uint32_t *blk_cnt = sp->blk_cnt;
     __shared__ uint32_t s_plan[MG_PLAN_LDS];
-    __shared__ uint32_t red[8];
+    __shared__ uint32_t red[4];
+    __shared__ __align__(16) u64 s_tile[MG_TILE_TERMS * MG_FORMULA_WORDS];
+    __shared__ uint32_t s_pre[MG_BLOCK], s_src[MG_BLOCK], s_trm[MG_BLOCK], s_scan[8];
     const uint32_t *plan = blob + plan_off;
     const bool in_lds = plan_len <= MG_PLAN_LDS;
+    const uint32_t win = blockIdx.x;
+    // first term group's lists: descriptor and window range of list (lb0 + lane) go out now, together
+    // with the plan, so that only the element loads remain behind the first barrier
+    const int tg0 = nt < MG_TILE_TERMS ? nt : MG_TILE_TERMS;
+    const uint32_t lb0 = sp->term_sl[0], le0 = sp->term_sl[tg0];
+    uint4 d0 = make_uint4(0, 0, 0, 0xFFFFFFFFu);
+    uint32_t r0s = 0, r0e = 0;
+    if (!empty && lb0 + threadIdx.x < le0) {
+        d0 = sl[lb0 + threadIdx.x];
+        r0e = d0.z;
+        if (d0.w != 0xFFFFFFFFu) { r0s = post_win[d0.w + win]; r0e = post_win[d0.w + win + 1]; }
+    }
     if (in_lds) {
         for (uint32_t i = threadIdx.x; i < plan_len; i += MG_BLOCK) s_plan[i] = plan[i];
         __syncthreads();
     }
-    // lane -> words: [2t, 2t+1] of the first 512 words and of the second 512 words of the chunk
-    const uint32_t base = blockIdx.x * MG_FORMULA_WORDS;
-    const uint32_t w0 = base + 2 * threadIdx.x, w1 = w0 + 512;
-    const bool in0 = w0 < Wp, in1 = w1 < Wp;
-    W4 v = {0, 0, 0, 0};
-    if (!empty && in0) {
-        uint32_t p = 0;
+    const uint32_t base = win * MG_FORMULA_WORDS;
+    const uint32_t w0 = base + 2 * threadIdx.x;
+    const bool in0 = w0 < Wp;
+    W2 v = {0, 0};
+    if (!empty) {                                 // uniform: the tile builder below synchronises the workgroup
+        int tcur = 0;
         auto word = [&](uint32_t i) -> uint32_t { return in_lds ? s_plan[i] : plan[i]; };
         auto row_of = [&](uint32_t e) -> const u64 * {
             return ((int32_t)e >= 0) ? dense + (size_t)e * Wp : rows + (size_t)(~e) * Wp;
         };
-        auto term = [&]() -> W4 {
-            W4 t = {0, 0, 0, 0};
-            const uint32_t n = word(p++);
-            for (uint32_t j = 0; j < n; j++) t = w4_or(t, w4_load(row_of(word(p++)), w0, w1, in0, in1));
-            return t;
+        auto build_tiles = [&](int t0) {
+            const int t1 = (t0 + MG_TILE_TERMS < nt) ? t0 + MG_TILE_TERMS : nt;
+            if (t0) __syncthreads();              // the previous group's tiles have been read
+            // ---- dense rows: this lane's words of each tile, nobody else touches them yet
+            u64 *mine = s_tile + 2 * threadIdx.x;
+            for (int j = 0; j < t1 - t0; j++) *(ulonglong2 *)(mine + j * MG_FORMULA_WORDS) = make_ulonglong2(0ull, 0ull);
+            const uint32_t dn0 = word((uint32_t)t0), dn1 = word((uint32_t)t1), lbase = (uint32_t)nt + 1;
+            for (uint32_t e = dn0; e < dn1; e += 4) {
+                uint32_t en[4]; ulonglong2 x[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) en[u] = (e + u < dn1) ? word(lbase + e + u) : 0xFFFFFFFFu;
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    x[u] = (en[u] != 0xFFFFFFFFu && in0) ? *(const ulonglong2 *)(dense + (size_t)(en[u] & 0x7FFFFFFu) * Wp + w0)
+                                                         : make_ulonglong2(0ull, 0ull);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (en[u] != 0xFFFFFFFFu) {
+                        u64 *tl = mine + ((en[u] >> 27) - (uint32_t)t0) * MG_FORMULA_WORDS;
+                        tl[0] |= x[u].x; tl[1] |= x[u].y;
+                    }
+                }
+            }
+            // ---- sparse lists
+            const uint32_t lb = t0 ? sp->term_sl[t0] : lb0, le = t0 ? sp->term_sl[t1] : le0;
+            for (uint32_t c = lb; c < le; c += MG_BLOCK) {
+                const uint32_t k = c + threadIdx.x;
+                uint32_t cnt = 0, src = 0, trm = 0;
+                if (k < le) {
+                    uint4 d = d0;                 // {term, first element, length, window index base}
+                    uint32_t s0 = r0s, e0 = r0e;
+                    if (t0 || c != lb) {
+                        d = sl[k];
+                        s0 = 0; e0 = d.z;
+                        if (d.w != 0xFFFFFFFFu) { s0 = post_win[d.w + win]; e0 = post_win[d.w + win + 1]; }
+                    }
+                    cnt = e0 - s0; src = d.y + s0;
+                    trm = (d.x - (uint32_t)t0) | (d.w == 0xFFFFFFFFu ? 0x100u : 0u);
+                }
+                uint32_t tot;
+                const uint32_t excl = block_excl_scan(cnt, &tot, s_scan);
+                s_pre[threadIdx.x] = (k < le) ? excl : 0xFFFFFFFFu;
+                s_src[threadIdx.x] = src; s_trm[threadIdx.x] = trm;
+                __syncthreads();                  // (also: every lane's dense words are in the tiles before the first OR)
+                for (uint32_t x = threadIdx.x; x < tot; x += MG_BLOCK) {
+                    // the list holding flat element x: the last one whose first element is <= x
+                    uint32_t j = 0;
+#pragma unroll
+                    for (uint32_t st = MG_BLOCK / 2; st > 0; st >>= 1) if (s_pre[j + st] <= x) j += st;
+                    const uint32_t d = post_doc[s_src[j] + (x - s_pre[j])];
+                    const uint32_t tr = s_trm[j];
+                    const uint32_t w = d >> 6;
+                    if ((tr & 0x100u) && (w / MG_FORMULA_WORDS) != win) continue;      // short list: other windows' docids
+                    // (32-bit halves of the little-endian u64 words)
+                    atomicOr((uint32_t *)s_tile + ((tr & 0xFFu) * MG_FORMULA_WORDS + (w - base)) * 2 + ((d >> 5) & 1u), 1u << (d & 31));
+                }
+                __syncthreads();
+            }
+        };
+        auto term = [&]() -> W2 {
+            if (tcur % MG_TILE_TERMS == 0) build_tiles(tcur);
+            const ulonglong2 x = *(const ulonglong2 *)(s_tile + (tcur % MG_TILE_TERMS) * MG_FORMULA_WORDS + 2 * threadIdx.x);
+            tcur++;
+            return {x.x, x.y};
         };
         if (nt == 1) v = term();
-        else if (nt == 3) { const W4 t0 = term(), t1 = term(), t2 = term(); v = w4_or(w4_and(t0, t1), t2); }
+        else if (nt == 3) { const W2 t0 = term(), t1 = term(), t2 = term(); v = w2_or(w2_and(t0, t1), t2); }
         else {
-            const W4 ones = {~0ull, ~0ull, ~0ull, ~0ull};
-            W4 acc = ones, prev = {0, 0, 0, 0};
+            const W2 ones = {~0ull, ~0ull};
+            W2 acc = ones, prev = {0, 0};
             for (int i = 0; i < nt; i += 2) {
-                W4 g = w4_or(prev, term());
-                W4 next = {0, 0, 0, 0};
-                if (i < nt - 2) { next = term(); g = w4_or(g, next); }
-                acc = w4_and(acc, g);
+                W2 g = w2_or(prev, term());
+                W2 next = {0, 0};
+                if (i < nt - 2) { next = term(); g = w2_or(g, next); }
+                acc = w2_and(acc, g);
                 prev = next;
             }
-            v = w4_or(acc, term());
+            v = w2_or(acc, term());
         }
         if (nf > 0) {
             // postfix filter program on a small register stack (static indexing only)
-            const W4 z = {0, 0, 0, 0};
-            W4 s0 = z, s1 = z, s2 = z, s3 = z, s4 = z, s5 = z, s6 = z, s7 = z;
+            const W2 z = {0, 0};
+            W2 s0 = z, s1 = z, s2 = z, s3 = z, s4 = z, s5 = z, s6 = z, s7 = z;
             for (int i = 0; i < nf; i++) {
                 const int op = (int)word(plan_fops + 2 * i);
                 const uint32_t a = word(plan_fops + 2 * i + 1);
                 if (op <= MGPU_F_PUSH_EMPTY) {
-                    W4 x = z;
-                    if (op != MGPU_F_PUSH_EMPTY) x = w4_load(row_of(a), w0, w1, in0, in1);
+                    W2 x = z;
+                    if (op != MGPU_F_PUSH_EMPTY) x = w2_load(row_of(a), w0, in0);
                     s7 = s6; s6 = s5; s5 = s4; s4 = s3; s3 = s2; s2 = s1; s1 = s0; s0 = x;
                 } else if (op == MGPU_F_DOCS_ANDNOT) {
-                    s0 = w4_andnot(v, s0);
+                    s0 = w2_andnot(v, s0);
                 } else {
-                    s0 = (op == MGPU_F_AND) ? w4_and(s1, s0) : w4_or(s1, s0);
+                    s0 = (op == MGPU_F_AND) ? w2_and(s1, s0) : w2_or(s1, s0);
                     s1 = s2; s2 = s3; s3 = s4; s4 = s5; s5 = s6; s6 = s7; s7 = z;
                 }
             }
-            v = w4_and(v, s0);
+            v = w2_and(v, s0);
         }
+        if (!in0) { v.a = 0; v.b = 0; }          // words past the row (the last window of a shard) hold nothing
     }
     if (in0) *(ulonglong2 *)(docid_map + w0) = make_ulonglong2(v.a, v.b);
-    if (in1) *(ulonglong2 *)(docid_map + w1) = make_ulonglong2(v.c, v.d);
-    // popcounts per 256-word block: wave k covers words [128k, 128k+128) of each half
+    // popcounts per 256-word block: waves 0,1 cover the window's first block, waves 2,3 its second
     const uint32_t c0 = wave_sum32((uint32_t)(__popcll(v.a) + __popcll(v.b)));
-    const uint32_t c1 = wave_sum32((uint32_t)(__popcll(v.c) + __popcll(v.d)));
-    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = c0; red[4 + (threadIdx.x >> 6)] = c1; }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c0;
     __syncthreads();
-    if (threadIdx.x < 4) {
+    if (threadIdx.x < MG_FORMULA_WORDS / MG_WORDS_PER_BLOCK) {
         const uint32_t b = blockIdx.x * (MG_FORMULA_WORDS / MG_WORDS_PER_BLOCK) + threadIdx.x;
         if (b < nblk) blk_cnt[b] = red[2 * threadIdx.x] + red[2 * threadIdx.x + 1];
     }
@@ -226,7 +304,7 @@ __global__ __launch_bounds__(MG_BLOCK) void k_scan(const SqDev *sqs, uint2 *tile
 }
 
 // bmap_iterate / cont_iterate (bmap.c:370-374, cont.c:590-610): bitmap -> ascending docid list.
-// Same work split as k_formula: 1024 words per workgroup, 2 x 16 bytes per lane.
+// 1024 words per workgroup, 2 x 16 bytes per lane.
 __device__ __forceinline__ void emit_bits(u64 v, uint32_t base, uint32_t *hits, uint32_t &off) {
     while (v) {
         const int b = __ffsll((long long)v) - 1;
@@ -237,7 +315,7 @@ __device__ __forceinline__ void emit_bits(u64 v, uint32_t base, uint32_t *hits, 
 __global__ __launch_bounds__(MG_BLOCK) void k_compact(const SqDev *sqs) {
     const SqDev *sp = &sqs[blockIdx.y];
     const uint32_t nblk = sp->nblk;
-    const uint32_t b0 = blockIdx.x * (MG_FORMULA_WORDS / MG_WORDS_PER_BLOCK);
+    const uint32_t b0 = blockIdx.x * (MG_COMPACT_WORDS / MG_WORDS_PER_BLOCK);
     if (b0 >= nblk) return;
     const uint32_t Wp = sp->sh.Wp;
     const u64 *docid_map = (const u64 *)sp->docid_map;
@@ -245,7 +323,7 @@ __global__ __launch_bounds__(MG_BLOCK) void k_compact(const SqDev *sqs) {
     uint32_t *hits = sp->hits;
     if (*sp->num_hits == 0) return;      // nothing to list (or k_scan refused the squery)
     __shared__ uint32_t lds[8];
-    const uint32_t w0 = blockIdx.x * MG_FORMULA_WORDS + 2 * threadIdx.x, w1 = w0 + 512;
+    const uint32_t w0 = blockIdx.x * MG_COMPACT_WORDS + 2 * threadIdx.x, w1 = w0 + 512;
     const ulonglong2 z = make_ulonglong2(0ull, 0ull);
     const ulonglong2 x = (w0 < Wp) ? *(const ulonglong2 *)(docid_map + w0) : z;
     const ulonglong2 y = (w1 < Wp) ? *(const ulonglong2 *)(docid_map + w1) : z;
@@ -1695,7 +1773,7 @@ int mgk_debug_clock_cal(unsigned long long *out3) {
 }
 // phase clocks: enable, and read + reset the 16 accumulators (100 MHz wall_clock64 ticks)
 int mgk_debug_phases(int on, unsigned long long *out16) {
-    unsigned long long z[24] = {0};
+    unsigned long long z[32] = {0};
     if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(mg_dbg_acc), sizeof(z)) != hipSuccess) return -1;
     if (hipMemcpyToSymbol(HIP_SYMBOL(mg_dbg_acc), z, sizeof(z)) != hipSuccess) return -1;
     if (hipMemcpyToSymbol(HIP_SYMBOL(mg_dbg_on), &on, sizeof(int)) != hipSuccess) return -1;
@@ -1714,7 +1792,7 @@ static uint32_t worklist_grid(uint32_t tile_cap) {
 }
 void mgk_formula(hipStream_t st, const SqDev *sqs, const uint32_t *blob, uint32_t max_nblk, uint32_t nsq,
                  uint2 *tile_list, uint32_t *tile_count) {
-    hipLaunchKernelGGL(k_formula, dim3((max_nblk + 3) / 4, nsq), dim3(MG_BLOCK), 0, st, sqs, blob);
+    hipLaunchKernelGGL(k_formula, dim3((max_nblk + 1) / 2, nsq), dim3(MG_BLOCK), 0, st, sqs, blob);
     hipLaunchKernelGGL(k_scan, dim3(nsq), dim3(MG_BLOCK), 0, st, sqs, tile_list, tile_count);
     hipLaunchKernelGGL(k_compact, dim3((max_nblk + 3) / 4, nsq), dim3(MG_BLOCK), 0, st, sqs);
 }

@@ -4,7 +4,10 @@
 #include "marlin_gpu.h"
 
 #define MG_BLOCK        256          // threads per workgroup (4 waves of 64)
-#define MG_WORDS_PER_BLOCK 256       // u64 bitmap words handled by one formula/compact block
+#define MG_WORDS_PER_BLOCK 256       // u64 bitmap words per hit-count block (blk_cnt granularity)
+#define MG_FORMULA_WORDS 512         // u64 bitmap words (= 32768 docids, one "window") owned by a formula workgroup
+#define MG_COMPACT_WORDS 1024        // u64 bitmap words turned into docids by a compact workgroup
+#define MG_SHORT_POSTING 32          // sparse postings up to this length carry no window index: every window scans them whole
 #define MG_MAX_STACK    8            // filter program stack depth
 #define MG_MCAP         8            // matched docwords kept per document in LDS before the overflow path
 #define MG_PCAP         12           // (slot,position) pairs per document in LDS before the overflow path
@@ -27,6 +30,9 @@ struct ShardDev {
     const int32_t  *post_dense;      // [num_postings] dense row index or -1
     const uint64_t *post_off;        // [num_postings + 1] into post_doc (sparse postings only)
     const uint32_t *post_doc;
+    // window index of the long sparse postings: post_win[base + j] = first element (relative to the posting's
+    // start) whose docid is >= j * 64 * MG_FORMULA_WORDS, j = 0..nwin (the last entry = the posting's length)
+    const uint32_t *post_win;
     // docwords: CSR over docids; entry = {wid, info}; info bit0 = single position inline
     const uint32_t *dw_off;          // [N + 1]
     const uint2    *dw;              // {wid, info}
@@ -87,9 +93,15 @@ struct SqDev {
     uint32_t term_dense_off[MGPU_MAX_TERMS + 1];   // into blob (u32 dense row indices)
     int32_t  term_row[MGPU_MAX_TERMS];             // scratch row index holding scattered sparse postings, or -1
     uint64_t *rows;                  // scratch rows [nrows][Wp], zeroed per query
-    // the same plan flattened for k_formula: per term {count, entries...}, entry >= 0 dense row, < 0 ~scratch row;
-    // then the filter ops {op, a} pairs.  plan_len u32 words at blob + plan_off.
+    // the plan flattened for k_formula, plan_len u32 words at blob + plan_off:
+    //   [0 .. num_terms]   dn[t]: dense rows of term t = list entries [dn[t], dn[t + 1])
+    //   [num_terms + 1 ..] the dense-row list, entry = row index | term << 27
+    //   [plan_fops ..]     the filter ops {op, a} pairs; a >= 0 dense row, < 0 ~scratch row
     uint32_t plan_off, plan_len, plan_fops;   // plan_fops: word index of the first filter op inside the plan
+    // sparse postings of the terms: 4 u32 per list {term, first element in post_doc, length, post_win base or ~0}
+    // at blob + sl_off (16-byte aligned), lists of term t = [term_sl[t], term_sl[t + 1])
+    uint32_t sl_off;
+    uint32_t term_sl[MGPU_MAX_TERMS + 1];
     // ---- filter ----
     int32_t  num_fops;
     uint32_t fops_off;               // into blob: 4 u32 per op {op, a, _, _}; operand a: dense row (>=0) or ~scratch row

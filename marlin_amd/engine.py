@@ -163,6 +163,21 @@ class GpuEngine:
             raise GpuError("msq_execute_prepared: %d %s" % (rc, self.lib.mgpu_last_error().decode()))
         return outs
 
+    def run_pipeline(self, preps, first, count, nthreads=None):
+        """`count` steps of the native serving loop (mplan.c:msq_run_pipeline): nthreads host threads, one
+        context each, step i = execute_prepared + form_result of preps[(first + i) % len(preps)];
+        returns the summed totalHits"""
+        nthreads = len(self.ctxs) if nthreads is None else nthreads
+        if nthreads > len(self.ctxs):
+            raise ValueError("more pipeline threads than contexts")
+        carr = (C.c_void_p * nthreads)(*self.ctxs[:nthreads])
+        parr = (C.c_void_p * len(preps))(*[p[0] for p in preps])
+        hits = C.c_long(0)
+        rc = self.lib.msq_run_pipeline(carr, nthreads, parr, len(preps), first, count, C.byref(hits))
+        if rc:
+            raise GpuError("msq_run_pipeline: %d %s" % (rc, self.lib.mgpu_last_error().decode()))
+        return hits.value
+
     def free_prepared(self, prep):
         self.lib.msq_prepared_free(prep[0])
 

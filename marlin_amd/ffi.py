@@ -167,6 +167,7 @@ def load():
         "msq_prepare_batch": (ci, [C.POINTER(vp), ci, C.POINTER(C.POINTER(Query)), ci, ci, C.POINTER(vp)]),
         "msq_execute_prepared": (ci, [vp, vp, C.POINTER(SqResult)]),
         "msq_prepared_free": (None, [vp]),
+        "msq_run_pipeline": (ci, [C.POINTER(vp), ci, C.POINTER(vp), ci, ci, ci, C.POINTER(C.c_long)]),
         # GPU C ABI (include/marlin_gpu.h), reached through the same process image
         "mgpu_last_error": (C.c_char_p, []),
         "mgpu_device_count": (ci, []),

@@ -441,3 +441,49 @@ int msq_execute_prepared(mgpu_ctx_t *ctx, const msq_prepared_t *pp, m_sqresult_t
     free(go);
     return rc;
 }
+
+/* ------------------------------------------------------------------ pipelined serving loop
+ * The shape query.c:319-383 has in the reference (a threadpool of workers, each running
+ * execute_squery jobs and handing them to form_result), with a batch as the unit of work:
+ * nthreads host threads, one GPU context each; thread t runs steps t, t + nthreads, ... and for each
+ * step executes prepared batch (first + step) % nprep and merges every query of it (form_result).
+ * Returns the first error code met (0 = none); *hits_out = sum of totalHits over all merged queries. */
+typedef struct {
+    mgpu_ctx_t *ctx; const msq_prepared_t *const *preps; int nprep, first, count, t, nthreads;
+    long hits; int rc;
+} pipe_job_t;
+
+static void *pipe_worker(void *arg) {
+    pipe_job_t *j = arg;
+    for (int i = j->t; i < j->count; i += j->nthreads) {
+        const msq_prepared_t *pp = j->preps[(j->first + i) % j->nprep];
+        m_sqresult_t *outs = calloc((size_t)(pp->n ? pp->n : 1), sizeof(m_sqresult_t));
+        if (!outs) { j->rc = -1; return NULL; }
+        int rc = msq_execute_prepared(j->ctx, pp, outs);
+        if (!rc) j->hits += m_form_result_batch((const m_query_t *const *)pp->queries, outs, pp->nq, pp->num_shards, NULL, 0);
+        m_sqresult_free_batch(outs, pp->n);
+        free(outs);
+        if (rc) { j->rc = rc; return NULL; }
+    }
+    return NULL;
+}
+
+int msq_run_pipeline(mgpu_ctx_t *const *ctxs, int nthreads, const msq_prepared_t *const *preps, int nprep,
+                     int first, int count, long *hits_out) {
+    if (nthreads < 1 || nthreads > 64 || nprep < 1 || count < 0) return -1;
+    pipe_job_t jobs[64];
+    pthread_t th[64];
+    for (int t = 0; t < nthreads; t++) {
+        jobs[t] = (pipe_job_t){ctxs[t], preps, nprep, first, count, t, nthreads, 0, 0};
+        if (nthreads > 1) pthread_create(&th[t], NULL, pipe_worker, &jobs[t]);
+    }
+    if (nthreads == 1) pipe_worker(&jobs[0]);
+    long hits = 0; int rc = 0;
+    for (int t = 0; t < nthreads; t++) {
+        if (nthreads > 1) pthread_join(th[t], NULL);
+        hits += jobs[t].hits;
+        if (jobs[t].rc && !rc) rc = jobs[t].rc;
+    }
+    if (hits_out) *hits_out = hits;
+    return rc;
+}

@@ -61,6 +61,10 @@ int  msq_prepare_batch(mmirror_t *const *mirrors, int num_shards, const m_query_
                        int nq, int capture, msq_prepared_t **out);
 int  msq_execute_prepared(mgpu_ctx_t *ctx, const msq_prepared_t *pp, m_sqresult_t *outs);
 void msq_prepared_free(msq_prepared_t *pp);
+/* serving loop: nthreads host threads (one context each) keep that many prepared batches in flight;
+ * step i runs batch (first + i) % nprep through execute_prepared + form_result (mplan.c) */
+int  msq_run_pipeline(mgpu_ctx_t *const *ctxs, int nthreads, const msq_prepared_t *const *preps, int nprep,
+                      int first, int count, long *hits_out);
 
 /* host threads used for plan building inside msq_execute_batch (default 1) */
 void msq_set_plan_threads(int n);

@@ -65,3 +65,23 @@ def test_result_independent_of_batching(zipf):
     for pq, b in zip(pqs, batched):
         a = eng.search(pq)
         assert a["ranks"] == b["ranks"] and a["facets"] == b["facets"] and a.get("aggs") == b.get("aggs"), pq.jq
+
+
+def test_sparse_postings_over_windows_and_term_groups(zipf):
+    """rare words: their postings stay sorted lists that k_formula ORs into LDS tiles window by window
+    (long lists through the window index, short ones scanned whole); four words make 8 terms = two
+    tile groups; a one-letter prefix expands to a hundred-odd lists in one term"""
+    lib, ix, eng = zipf
+    r = [word(lib, k) for k in (300, 700, 1500, 2500, 3500, 4000)]
+    qs = [
+        {"q": " ".join(r[:4]), "hitsPerPage": 50},
+        {"q": r[4] + " " + r[5] + " " + r[2], "rankBy": {"num": "desc"}},
+        {"q": r[1] + " " + r[3][:1], "hitsPerPage": 30},                       # broad prefix on the last word
+        {"q": r[5][:-1] + ("q" if r[5][-1] != "q" else "z") + " " + r[0], "maxFacetResults": 5},     # typo on a rare word
+        {"q": r[2], "filter": {"cat": "cat01"}, "rankBy": {"price": "asc"}},
+    ]
+    pqs = [ix.query(dict(jq, fullScan=True)) for jq in qs]
+    got = eng.search(pqs, capture=3)
+    for pq, g in zip(pqs, got):
+        compare_results(g, orc_py.search(ix, pq, flags=3), ctx=pq.jq)
+    assert any(g["totalHits"] > 0 for g in got)

@@ -29,7 +29,7 @@ gpu.mgk_debug_phases(1, None)
 for _ in range(1):
     eng.free_raw(eng.execute_prepared(prep))
 print("stage ms (with phase clocks):", {k: round(x["ms"], 4) for k, x in eng.timing()["stages"].items()})
-out = (C.c_ulonglong * 24)()
+out = (C.c_ulonglong * 32)()
 gpu.mgk_debug_phases(0, out)
 v = list(out)
 tiles = max(1, v[3]); jobs = max(1, v[8])
@@ -40,6 +40,8 @@ for slot, name in ((13, "ANY exit WG"), (9, "whole WG"), (10, "final"), (11, "mi
     print("select max %s: %.1f us at M=%d" % (name, (v[slot] >> 32) / 100, v[slot] & 0xFFFFFFFF))
 mj = max(1, v[21])
 print("mid select jobs %d, passes %.2f per job, us per job: setup %.2f sweeps %.2f decide %.2f final %.2f" % (v[21], v[22] / mj, v[17] / mj / 100, v[18] / mj / 100, v[19] / mj / 100, v[20] / mj / 100))
+fw = max(1, v[24])
+print("formula workgroups %d: lists %.1f, elements %.1f per workgroup; us per workgroup: before first barrier %.2f, tiles + formula %.2f" % (v[24], v[25] / fw, v[26] / fw, v[27] / fw / 100, v[28] / fw / 100))
 cal = (C.c_ulonglong * 3)()
 gpu.mgk_debug_clock_cal.argtypes = [C.POINTER(C.c_ulonglong)]
 gpu.mgk_debug_clock_cal(cal)
