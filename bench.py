@@ -269,7 +269,7 @@ def main():
         ms, by = acc[k][0] / nprof, acc[k][1] / nprof
         stage_tab[k] = {"ms": round(ms, 4), "MB": round(by / 1e6, 3), "GBps": round(by / ms / 1e6, 1) if ms > 0 else None}
     ach = acc[dom][1] / acc[dom][0] / 1e6          # bytes / ms -> GB/s
-    KERNELS = {"rank": "k_rank_tile + k_rank_overflow", "select": "k_select_pass", "formula+compact": "k_formula + k_scan + k_compact",
+    KERNELS = {"rank": "k_rank_tile + k_rank_overflow", "select": "k_select_first + k_select_mid (+ k_select_items, k_select_final)", "formula+compact": "k_formula + k_scan + k_compact",
                "facets+aggs": "k_docproc + k_aggfinal", "facet-keys": "k_fkeys + k_card", "scatter": "k_scatter"}
     # HBM traffic of the dominant kernel comes from separate PMC passes (rocprofv3 cannot run inside the
     # timed program): profiles/r01_pmc_fetch_write_per_launch.json, same command and batch size
