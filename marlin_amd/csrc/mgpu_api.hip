@@ -25,7 +25,7 @@ void mgk_rank(hipStream_t st, const SqDev *sqs, const uint32_t *blob, uint32_t m
               uint32_t max_tab_slots, const uint2 *tile_list, const uint32_t *tile_count, uint32_t tile_cap,
               unsigned long long *pool, uint32_t *pool_used, uint64_t pool_cap);
 void mgk_docproc(hipStream_t st, const SqDev *sqs, uint32_t nsq, const uint2 *tile_list, const uint32_t *tile_count,
-                 uint32_t tile_cap);
+                 uint32_t tile_cap, uint32_t lds_bins);
 void mgk_fkeys(hipStream_t st, const void *jobs, uint32_t njobs, uint32_t max_n);
 void mgk_card(hipStream_t st, const void *jobs, uint32_t njobs, uint32_t max_n);
 void mgk_select(hipStream_t st, const SelJob *jobs, const void *outs, uint32_t njobs, uint32_t max_m, int passes, int finals,
@@ -505,10 +505,10 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
     Bump zer;          // rest of the zero region
     Bump nz;           // non-zero region
     std::vector<int> nrows(n, 0);
-    uint32_t max_nblk = 1, max_N = 1, max_pblocks = 1, max_fk = 1, max_selm = 1, max_tab = 1, max_fac_k = 0, max_fac_nord = 0;
+    uint32_t max_nblk = 1, max_N = 1, max_pblocks = 1, max_fk = 1, max_selm = 1, max_tab = 1, max_fac_k = 0, max_fac_nord = 0, max_lds_bins = 0;
 
     struct Offs {      // arena offsets per squery (zero or nonzero region relative)
-        size_t rows, hist[MGPU_MAX_FIELDS], touched[MGPU_MAX_FIELDS], ntouched[MGPU_MAX_FIELDS], andor, ovfcnt, docmap, blk, hits, khi, klo, ovfl, aggpart;
+        size_t rows, hist[MGPU_MAX_FIELDS], touched[MGPU_MAX_FIELDS], ntouched[MGPU_MAX_FIELDS], facord[MGPU_MAX_FIELDS], andor, ovfcnt, docmap, blk, hits, khi, klo, ovfl, aggpart;
         size_t fkhi[MGPU_MAX_FIELDS], fklo[MGPU_MAX_FIELDS];
     };
     std::vector<Offs> offs(n);
@@ -745,8 +745,10 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
         o.rows = 0;   // filled after nrows is final (below)
         for (int f = 0; f < sd.num_facets; f++) if ((hmask >> f) & 1u) {
             o.hist[f] = zer.take((size_t)sd.fa_nord[f] * 4 + 4);
+            if (sd.fa_nord[f] <= MG_LDS_HIST) max_lds_bins = std::max(max_lds_bins, sd.fa_nord[f]);
             o.ntouched[f] = zer.take(4, 4);
             o.touched[f] = nz.take((size_t)sd.fa_nord[f] * 4 + 4);
+            o.facord[f] = nz.take((size_t)std::max<uint32_t>(q.hit_cap, 1) * 4);
         }
         o.andor = zer.take(32); o.ovfcnt = zer.take(4);
         o.docmap = nz.take((size_t)sd.Wp * 8); o.blk = nz.take((size_t)(q.nblk + 1) * 4);
@@ -855,6 +857,7 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
             q.hist[f] = (uint32_t *)(Z + o.hist[f]);
             q.ntouched[f] = (uint32_t *)(Z + o.ntouched[f]);
             q.touched[f] = (uint32_t *)(NZ + o.touched[f]);
+            q.fac_ord[f] = (uint32_t *)(NZ + o.facord[f]);
         }
         q.agg_part = (AggPart *)(NZ + o.aggpart);
         q.agg_out = hdr->agg;
@@ -916,6 +919,15 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
     }
     // need_keys: the rank kernel has nothing to do when no hits are requested
     for (int i = 0; i < n; i++) if (!sqh[i].k) sqd[i].do_rank = -1;
+    // facet counting rides on the rank kernel's record visit whenever that kernel reads the records
+    {
+        const bool fuse = !getenv("MGPU_NO_FUSED_FACETS");
+        for (int i = 0; i < n; i++) {
+            SqDev &q = sqd[i];
+            const bool reads_records = q.do_rank == 1 || (q.do_rank == 0 && q.rank_by >= 0 && (uint32_t)q.rank_by < q.sh.rec_nnum);
+            q.fac_in_rank = (fuse && q.hist_mask && reads_records) ? 1 : 0;
+        }
+    }
 
     // staging copy
     memcpy(c->pin + up_sq, sqd.data(), sizeof(SqDev) * n);
@@ -951,7 +963,7 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
     mark();
     mgk_rank(st, d_sq, d_blob, max_N, (uint32_t)n, max_tab, d_tiles, d_tilecnt, (uint32_t)tile_cap, c->pool, c->pool_used, c->pool_cap);
     mark();
-    mgk_docproc(st, d_sq, (uint32_t)n, d_tiles, d_tilecnt, (uint32_t)tile_cap);
+    mgk_docproc(st, d_sq, (uint32_t)n, d_tiles, d_tilecnt, (uint32_t)tile_cap, max_lds_bins);
     mark();
     mgk_fkeys(st, UP + up_fk, (uint32_t)fkjobs.size(), max_fk);
     mgk_card(st, UP + up_card, (uint32_t)cardjobs.size(), max_fk);

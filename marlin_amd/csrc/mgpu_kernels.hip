@@ -575,6 +575,17 @@ __device__ __forceinline__ void or_key_bits(u64 *key_andor, u64 a, u64 b, u64 na
 // knows -- a handful per document -- as records in LDS.  Phase 2 ranks one document per lane from
 // its records.  Documents with more matches or positions than the LDS slices hold go to the
 // overflow list and are ranked by k_rank_overflow.
+// appends `v` to list[*n] for every lane whose `pred` is set, with one atomic per wave
+__device__ __forceinline__ void wave_append(bool pred, uint32_t v, uint32_t *list, uint32_t *n) {
+    const u64 m = __ballot(pred);
+    if (!m) return;
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+    uint32_t at = 0;
+    if (lane == leader) at = atomicAdd(n, (uint32_t)__popcll(m));
+    at = __shfl(at, leader, 64);
+    if (pred) list[at + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = v;
+}
+
 extern __shared__ uint2 dyn_tab[];
 __global__ __launch_bounds__(MG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_rank_tile(const SqDev *sqs, const uint32_t *blob,
                                                         const uint2 *tile_list, const uint32_t *tile_count) {
@@ -609,6 +620,9 @@ __global__ __launch_bounds__(MG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
         uint32_t *p_ovf_cnt = sp->ovf_cnt, *p_ovf_list = sp->ovf_list;
         const KeyLayout kl = load_key_layout(sp);
         const double *col = sp->sh.num_col[rb >= 0 ? rb : 0];
+        const int fac_here = sp->fac_in_rank;
+        const uint32_t fac_mask = sp->hist_mask;
+        const int nfac = sp->sh.num_facets;
         if (do_rank < 0) continue;                   // no hits requested: nobody reads the keys
         const uint32_t M = *p_num_hits;
         const uint2 *gtab = (const uint2 *)(blob + hash_off);
@@ -662,6 +676,18 @@ __global__ __launch_bounds__(MG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                     const uint32_t h3 = __shfl(v[k].w, 0, 16);
                     const uint32_t nin = h0 >> 16, ws = h3 >> 16;
                     if (gl == 0) s_pbase[d] = h1;
+                    if (fac_here) {
+                        // the record's facet section (from word 4 + 2 * rec_nnum) is staged in the pair slices,
+                        // which are idle until phase 1b; s_np carries "the section is in the record"
+                        if (gl == 0) s_np[d] = (h3 >> 8) & 1u;
+                        const int x0 = 4 * (int)gl - (int)(4 + 2 * rec_nnum);
+                        if (x0 > -4 && x0 < MG_PCAP) {
+                            if (x0 >= 0 && x0 < MG_PCAP) s_pairs[x0 * MG_BLOCK + d] = v[k].x;
+                            if (x0 + 1 >= 0 && x0 + 1 < MG_PCAP) s_pairs[(x0 + 1) * MG_BLOCK + d] = v[k].y;
+                            if (x0 + 2 >= 0 && x0 + 2 < MG_PCAP) s_pairs[(x0 + 2) * MG_BLOCK + d] = v[k].z;
+                            if (x0 + 3 >= 0 && x0 + 3 < MG_PCAP) s_pairs[(x0 + 3) * MG_BLOCK + d] = v[k].w;
+                        }
+                    }
                     if (val_in_rec && gl == (uint32_t)(1 + (rb >> 1))) {
                         const u64 bits = (rb & 1) ? (((u64)v[k].w << 32) | v[k].z) : (((u64)v[k].y << 32) | v[k].x);
                         s_val[d] = __longlong_as_double((long long)bits);
@@ -729,6 +755,30 @@ __global__ __launch_bounds__(MG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
             }
             __syncthreads();
             DBG_T(t2); DBG_ADD(1, t1, t2);
+            // Phase 1c, one lane per document: the hit's facet ordinals (process_facet_result, docrank.c:371-389)
+            // go from the staged section into fac_ord, so that k_docproc counts them from a coalesced array
+            // instead of visiting the same record a second time.  Anything but "one value, staged" is left to
+            // k_docproc's own lookup.
+            if (fac_here) {
+                if (valid) {
+                    const bool in_rec = s_np[tid] & 1u;
+                    const uint32_t hist_mask = fac_mask;
+                    uint32_t pos = 0;
+                    bool staged_ok = in_rec;
+                    for (int f = 0; f < nfac; f++) {
+                        uint32_t code = MG_FAC_LOOKUP;
+                        if (staged_ok && pos < MG_PCAP) {
+                            const uint32_t cnt = s_pairs[pos * MG_BLOCK + tid];
+                            if (cnt == 0) code = MG_FAC_NONE;
+                            else if (cnt == 1 && pos + 1 < MG_PCAP) code = s_pairs[(pos + 1) * MG_BLOCK + tid];
+                            pos += 1 + cnt;
+                        } else staged_ok = false;
+                        if ((hist_mask >> f) & 1u) sp->fac_ord[f][t] = code;
+                    }
+                }
+                s_np[tid] = 0;
+                __syncthreads();
+            }
             // Phase 1b, one lane per match record: fetch the word's positions (the only dependent
             // global read of the ranking, issued for all records of the tile at once), turn them into
             // (slot, position) pairs in the document's LDS slice and leave {val, first position}
@@ -837,23 +887,13 @@ __global__ __launch_bounds__(MG_BLOCK) void k_rank_overflow(const SqDev *sqs, co
     or_key_bits((u64 *)sq.key_andor, a, b, na, nb);
 }
 
-// appends `v` to list[*n] for every lane whose `pred` is set, with one atomic per wave
-__device__ __forceinline__ void wave_append(bool pred, uint32_t v, uint32_t *list, uint32_t *n) {
-    const u64 m = __ballot(pred);
-    if (!m) return;
-    const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
-    uint32_t at = 0;
-    if (lane == leader) at = atomicAdd(n, (uint32_t)__popcll(m));
-    at = __shfl(at, leader, 64);
-    if (pred) list[at + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = v;
-}
 
 // ------------------------------------------------------------------ facets + aggregations
 // process_facet_result (docrank.c:371-389) and consume_*_agg (metric-aggs.c) over the hit list.
 // Facet ids were turned into dense ordinals by the mirror, so the hashtable of hashtable.c
 // becomes a histogram: privatised in LDS when the field has <= MG_LDS_HIST values.
-__global__ __launch_bounds__(MG_BLOCK) void k_docproc(const SqDev *sqs, const uint2 *tile_list, const uint32_t *tile_count) {
-    __shared__ uint32_t hist[MG_LDS_HIST];
+__global__ __launch_bounds__(MG_BLOCK) void k_docproc(const SqDev *sqs, const uint2 *tile_list, const uint32_t *tile_count, uint32_t lds_bins) {
+    uint32_t *hist = (uint32_t *)dyn_tab;        // lds_bins words of dynamic LDS: the largest field of the batch that is privatised
     __shared__ AggPart red[MG_BLOCK / 64];
     const uint32_t ntiles = *tile_count;
     for (uint32_t w = blockIdx.x; w < ntiles; w += gridDim.x) {
@@ -866,6 +906,7 @@ __global__ __launch_bounds__(MG_BLOCK) void k_docproc(const SqDev *sqs, const ui
         // tiles beyond the slice count have nothing to add.
         const uint32_t nvb = sq.nproc_blocks, vb = item.y;
         if (vb >= nvb || (sq.hist_mask == 0 && sq.num_aggs == 0)) continue;
+        const bool have_ords = sq.fac_in_rank != 0;
         const uint32_t M = *sq.num_hits;
         const uint32_t stride = nvb * MG_BLOCK;
 
@@ -879,15 +920,24 @@ __global__ __launch_bounds__(MG_BLOCK) void k_docproc(const SqDev *sqs, const ui
             const uint32_t *ord = sq.sh.fa_ord[f];
             uint32_t *gh = sq.hist[f];
             uint32_t *tl = sq.touched[f], *tn = sq.ntouched[f];
-            const bool use_lds = nord <= MG_LDS_HIST;
+            const bool use_lds = nord <= lds_bins;
             if (use_lds) {
                 for (uint32_t i = threadIdx.x; i < nord; i += MG_BLOCK) hist[i] = 0;
                 __syncthreads();
             }
+            const uint32_t *ords = have_ords ? sq.fac_ord[f] : nullptr;
             for (uint32_t i = vb * MG_BLOCK + threadIdx.x; i < M; i += stride) {
+                // the rank kernel left the hit's ordinal behind (one value, the common case) ...
+                const uint32_t code = have_ords ? ords[i] : MG_FAC_LOOKUP;
+                if (code == MG_FAC_NONE) continue;
+                if (code != MG_FAC_LOOKUP) {
+                    if (use_lds) atomicAdd(&hist[code], 1u);
+                    else wave_append(atomicAdd(&gh[code], 1u) == 0, code, tl, tn);
+                    continue;
+                }
+                // ... else the document's ordinals for field f come from its record when they fit there, else
+                // from the per-field CSR
                 const uint32_t d = sq.hits[i];
-                // the document's ordinals for field f: from its record when they fit there (the line
-                // the rank stage just read), else from the per-field CSR
                 const uint32_t *r = rec + (size_t)d * S4;
                 const uint32_t *vals; uint32_t cnt;
                 if ((r[3] >> 8) & 1u) {
@@ -1807,9 +1857,12 @@ void mgk_rank(hipStream_t st, const SqDev *sqs, const uint32_t *blob, uint32_t m
     if (gy > cap) gy = cap;
     hipLaunchKernelGGL(k_rank_overflow, dim3(gy, nsq), dim3(MG_BLOCK), 0, st, sqs, blob, pool, pool_used, pool_cap);
 }
+// lds_bins: the largest histogram of the batch that has at most MG_LDS_HIST bins (those are privatised in LDS;
+// sizing the LDS by it instead of by the limit keeps more workgroups per CU when the small fields are small)
 void mgk_docproc(hipStream_t st, const SqDev *sqs, uint32_t nsq, const uint2 *tile_list, const uint32_t *tile_count,
-                 uint32_t tile_cap) {
-    hipLaunchKernelGGL(k_docproc, dim3(worklist_grid(tile_cap)), dim3(MG_BLOCK), 0, st, sqs, tile_list, tile_count);
+                 uint32_t tile_cap, uint32_t lds_bins) {
+    if (lds_bins > MG_LDS_HIST) lds_bins = MG_LDS_HIST;
+    hipLaunchKernelGGL(k_docproc, dim3(worklist_grid(tile_cap)), dim3(MG_BLOCK), (size_t)lds_bins * 4, st, sqs, tile_list, tile_count, lds_bins);
     hipLaunchKernelGGL(k_aggfinal, dim3(nsq), dim3(64), 0, st, sqs);
 }
 void mgk_fkeys(hipStream_t st, const void *jobs, uint32_t njobs, uint32_t max_n) {

@@ -77,6 +77,8 @@ struct SelJob {                      // one top-k selection (rank keys of a sque
     // the selecting workgroup may fill; NULL = the keys are already in key_hi/key_lo
     const uint32_t *gen_touched, *gen_hist, *gen_ord2id;
 };
+#define MG_FAC_NONE   0xFFFFFFFFu     // fac_ord: the document has no value in the field
+#define MG_FAC_LOOKUP 0xFFFFFFFEu     // fac_ord: several values, or not staged: k_docproc reads the record / CSR itself
 #define MG_SEL_MID_KEYS 131072u      // longest fresh list one 1024-thread workgroup selects (k_select_mid)
 #define MG_SEL_SOLO_K 256u           // largest k of the one-workgroup selections
 // ctl words
@@ -125,6 +127,8 @@ struct SqDev {
     uint32_t *ovf_list;              // [N] hit indices whose position lists overflowed
     // ---- doc processing (facets + aggs) ----
     uint32_t hist_mask;              // bit f: histogram field f
+    int32_t  fac_in_rank;            // the rank kernel leaves every hit's facet ordinals in fac_ord while it holds the records
+    uint32_t *fac_ord[MGPU_MAX_FIELDS];   // [hit_cap] per histogram field: the hit's ordinal, MG_FAC_NONE, or MG_FAC_LOOKUP
     uint32_t *hist[MGPU_MAX_FIELDS]; // [fa_nord[f]] zeroed per query
     uint32_t *touched[MGPU_MAX_FIELDS];  // [fa_nord[f]] bins hit at least once, in first-touch order
     uint32_t *ntouched[MGPU_MAX_FIELDS]; // device word, zeroed per query
