@@ -79,6 +79,16 @@ def test_facet_keys_by_separate_kernel(dg, monkeypatch):
         compare_results(g, orc_py.search(ix, pq, flags=3), ctx=pq.jq)
 
 
+def test_facets_counted_without_the_rank_kernels_ordinals(dg, monkeypatch):
+    """k_docproc looks every facet value up itself (the path of squeries whose rank stage reads no records)"""
+    ix, eng = dg
+    monkeypatch.setenv("MGPU_NO_FUSED_FACETS", "1")
+    pqs = [ix.query(dict(jq, fullScan=True)) for jq in DG_QUERIES]
+    got = eng.search(pqs, capture=3)
+    for pq, g in zip(pqs, got):
+        compare_results(g, orc_py.search(ix, pq, flags=3), ctx=pq.jq)
+
+
 def test_many_facet_results_need_the_big_final_sort(dg):
     """2 * maxFacetResults above the one-workgroup selection's k: keys by k_fkeys, wide passes + big sort"""
     ix, eng = dg
