@@ -28,6 +28,7 @@ void mgk_docproc(hipStream_t st, const SqDev *sqs, uint32_t nsq, const uint2 *ti
                  uint32_t tile_cap, uint32_t lds_bins);
 void mgk_fkeys(hipStream_t st, const void *jobs, uint32_t njobs, uint32_t max_n);
 void mgk_card(hipStream_t st, const void *jobs, uint32_t njobs, uint32_t max_n);
+void mgk_check_zero(hipStream_t st, const void *p, size_t bytes, uint32_t *flag);
 void mgk_select(hipStream_t st, const SelJob *jobs, const void *outs, uint32_t njobs, uint32_t max_m, int passes, int finals,
                 void *items_mem, uint32_t cap_items, uint32_t *counters, uint32_t *fin_list);
 void mgk_row_op(hipStream_t st, const unsigned long long *a, const unsigned long long *b, unsigned long long *out,
@@ -36,7 +37,8 @@ void mgk_row_op(hipStream_t st, const unsigned long long *a, const unsigned long
 
 struct FkJob { const uint32_t *hist; const uint32_t *ord2id; const uint32_t *touched; const uint32_t *ntouched;
                u64 *key_hi, *key_lo; u64 *andor; };
-struct CardJob { const uint32_t *ord2id; const uint32_t *touched; const uint32_t *ntouched; uint32_t *out_ids; uint32_t *out_n; };
+struct CardJob { const uint32_t *ord2id; const uint32_t *touched; const uint32_t *ntouched; uint32_t *out_ids; uint32_t *out_n;
+                 uint32_t *clean_hist; };   // histogram to put back to zero (fields no facet job consumes), or NULL
 struct SelOut { u64 *out_hi, *out_lo; uint32_t *out_pl; const uint32_t *payload; };
 
 static thread_local std::string g_err;
@@ -309,6 +311,10 @@ struct mgpu_ctx {
     char *pin = nullptr; size_t pin_cap = 0;          // pinned staging for uploads
     char *pin_out = nullptr; size_t pin_out_cap = 0;  // pinned buffer for results
     u64 *pool = nullptr; uint64_t pool_cap = 0;       // overflow position pool, in u64 entries
+    // Self-cleaned pool: facet histograms and select histograms.  It is all zero between batches because
+    // every kernel that consumes a bin puts the zero back (k_fkeys / the select kernels / k_card; the wide
+    // select passes); a batch that does not run to its end leaves `cln_dirty` set and the next one clears it.
+    Arena cln; bool cln_dirty = true;
     uint32_t *pool_used = nullptr;
     hipEvent_t ev[MGPU_NUM_STAGES + 1];
     int profiling;
@@ -339,6 +345,7 @@ extern "C" void mgpu_ctx_destroy(mgpu_ctx_t *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->arena.dev) (void)hipFree(c->arena.dev);
+    if (c->cln.dev) (void)hipFree(c->cln.dev);
     if (c->pin) (void)hipHostFree(c->pin);
     if (c->pin_out) (void)hipHostFree(c->pin_out);
     (void)hipFree(c->pool); (void)hipFree(c->pool_used);
@@ -504,6 +511,7 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
     Bump res;          // results region (inside the zero region, first)
     Bump zer;          // rest of the zero region
     Bump nz;           // non-zero region
+    Bump cln;          // self-cleaned pool (its own allocation, see mgpu_ctx)
     std::vector<int> nrows(n, 0);
     uint32_t max_nblk = 1, max_N = 1, max_pblocks = 1, max_fk = 1, max_selm = 1, max_tab = 1, max_fac_k = 0, max_fac_nord = 0, max_lds_bins = 0;
 
@@ -744,7 +752,7 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
         }
         o.rows = 0;   // filled after nrows is final (below)
         for (int f = 0; f < sd.num_facets; f++) if ((hmask >> f) & 1u) {
-            o.hist[f] = zer.take((size_t)sd.fa_nord[f] * 4 + 4);
+            o.hist[f] = cln.take((size_t)sd.fa_nord[f] * 4 + 4);
             if (sd.fa_nord[f] <= MG_LDS_HIST) max_lds_bins = std::max(max_lds_bins, sd.fa_nord[f]);
             o.ntouched[f] = zer.take(4, 4);
             o.touched[f] = nz.take((size_t)sd.fa_nord[f] * 4 + 4);
@@ -776,7 +784,7 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
             h.rank_job = (int)seloff.size();
             SelOff so; so.mcap = q.hit_cap;
             so.cand0 = nz.take(hc * 4); so.cand1 = nz.take(hc * 4);
-            so.hist = zer.take(MG_SEL_BINS * 4); so.ctl = zer.take(SEL_WORDS * 4); so.outidx = nz.take((size_t)MG_SEL_FINAL * 4);
+            so.hist = cln.take(MG_SEL_BINS * 4); so.ctl = zer.take(SEL_WORDS * 4); so.outidx = nz.take((size_t)MG_SEL_FINAL * 4);
             seloff.push_back(so); jobfix.push_back({i, 0, 0});
             max_selm = std::max(max_selm, q.hit_cap);
         }
@@ -785,7 +793,7 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
             h.fac_job[j] = (int)seloff.size();
             SelOff so; so.mcap = sd.fa_nord[f];
             so.cand0 = nz.take((size_t)so.mcap * 4); so.cand1 = nz.take((size_t)so.mcap * 4);
-            so.hist = zer.take(MG_SEL_BINS * 4); so.ctl = zer.take(SEL_WORDS * 4); so.outidx = nz.take((size_t)MG_SEL_FINAL * 4);
+            so.hist = cln.take(MG_SEL_BINS * 4); so.ctl = zer.take(SEL_WORDS * 4); so.outidx = nz.take((size_t)MG_SEL_FINAL * 4);
             so.andor = zer.take(32, 8);
             seloff.push_back(so); jobfix.push_back({i, 1, j});
             max_selm = std::max(max_selm, so.mcap);
@@ -834,6 +842,16 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
     int rc = ensure_arena(c, total);
     if (rc) return rc;
     if ((rc = ensure_pin(&c->pin, &c->pin_cap, up_bytes))) return rc;
+    const size_t cln_bytes = (cln.off + 255) / 256 * 256;
+    if (cln_bytes > c->cln.cap) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (c->cln.dev) HIPCHK(hipFree(c->cln.dev));
+        c->cln.dev = nullptr; c->cln.cap = 0; c->cln_dirty = true;
+        const size_t cap = std::max(cln_bytes + cln_bytes / 4, (size_t)(1u << 20));
+        HIPCHK(hipMalloc((void **)&c->cln.dev, cap));
+        c->cln.cap = cap;
+    }
+    char *CL = c->cln.dev;
     if ((rc = ensure_pin(&c->pin_out, &c->pin_out_cap, res_bytes))) return rc;
     char *A = c->arena.dev;
     char *R = A;                       // results region
@@ -854,7 +872,7 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
         q.key_andor = (uint64_t *)(Z + o.andor);
         q.ovf_list = (uint32_t *)(NZ + o.ovfl);
         for (int f = 0; f < q.sh.num_facets; f++) if ((q.hist_mask >> f) & 1u) {
-            q.hist[f] = (uint32_t *)(Z + o.hist[f]);
+            q.hist[f] = (uint32_t *)(CL + o.hist[f]);
             q.ntouched[f] = (uint32_t *)(Z + o.ntouched[f]);
             q.touched[f] = (uint32_t *)(NZ + o.touched[f]);
             q.fac_ord[f] = (uint32_t *)(NZ + o.facord[f]);
@@ -884,7 +902,7 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
         SelJob &sj = seljobs[j]; SelOut &so2 = selouts[j];
         memset(&sj, 0, sizeof(sj));
         sj.cand[0] = (uint32_t *)(NZ + so.cand0); sj.cand[1] = (uint32_t *)(NZ + so.cand1);
-        sj.hist = (uint32_t *)(Z + so.hist); sj.ctl = (uint32_t *)(Z + so.ctl);
+        sj.hist = (uint32_t *)(CL + so.hist); sj.ctl = (uint32_t *)(Z + so.ctl);
         sj.out_idx = (uint32_t *)(NZ + so.outidx); sj.m_cap = so.mcap;
         if (jf.kind == 0) {
             sj.key_hi = q.key_hi; sj.key_lo = q.key_lo; sj.m_ptr = q.num_hits; sj.k = h.k;
@@ -914,6 +932,10 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
             int f = q.agg_field[h.card_agg[j]];
             CardJob cj; cj.ord2id = q.sh.fa_ord2id[f]; cj.touched = q.touched[f]; cj.ntouched = q.ntouched[f];
             cj.out_ids = (uint32_t *)(A + nz_base + h.card_ids_off[j]); cj.out_n = &hdr->card_n[j];
+            bool has_facet_job = false, seen = false;
+            for (int x = 0; x < h.nfac; x++) has_facet_job |= h.fac_field[x] == f;
+            for (int x = 0; x < j; x++) seen |= q.agg_field[h.card_agg[x]] == f;          // two cardinality aggs on one field
+            cj.clean_hist = (has_facet_job || seen) ? nullptr : q.hist[f];
             cardjobs.push_back(cj);
         }
     }
@@ -953,6 +975,8 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
     auto mark = [&]() { if (prof) (void)hipEventRecord(c->ev[evi++], st); };
     (void)hipEventRecord(c->ev[0], st); evi = 1;
     HIPCHK(hipMemsetAsync(A, 0, zero_bytes, st));
+    if (c->cln_dirty && c->cln.cap) HIPCHK(hipMemsetAsync(CL, 0, c->cln.cap, st));
+    c->cln_dirty = true;                  // until this batch has run to its end
     HIPCHK(hipMemsetAsync(c->pool_used, 0, 4, st));
     HIPCHK(hipMemcpyAsync(UP, c->pin, up_bytes, hipMemcpyHostToDevice, st));
     mark();
@@ -1084,6 +1108,17 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
         if (h.k) c->stage_bytes[6] += 16 * M * (M > MG_SEL_SMALL ? 2 : 1);
     }
     c->stage_bytes[0] = up_bytes; c->stage_bytes[7] = res_bytes;
+    // the batch ran to its end: the self-cleaned pool is zero again (MGPU_CHECK_CLEAN makes sure of it)
+    c->cln_dirty = false;
+    if (getenv("MGPU_CHECK_CLEAN") && c->cln.cap) {
+        uint32_t *flag = (uint32_t *)A;              // the arena is free again
+        HIPCHK(hipMemsetAsync(flag, 0, 4, st));
+        mgk_check_zero(st, CL, c->cln.cap, flag);
+        uint32_t hflag = 0;
+        HIPCHK(hipMemcpyAsync(&hflag, flag, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (hflag) { c->cln_dirty = true; return fail(MGPU_E_HIP, "self-cleaned pool was left dirty by this batch"); }
+    }
     c->host_ms[0] = (float)(t_lowered - t_begin); c->host_ms[1] = (float)(t_waited - t_lowered);
     c->host_ms[2] = (float)(wall_ms() - t_waited);
     return worst;

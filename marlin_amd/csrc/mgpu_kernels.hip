@@ -1026,7 +1026,8 @@ __global__ __launch_bounds__(MG_BLOCK) void k_fkeys(const FkJob *jobs) {
     u64 a = 0, b = 0, na = 0, nb = 0;
     for (uint32_t i = blockIdx.x * MG_BLOCK + threadIdx.x; i < n; i += gridDim.x * MG_BLOCK) {
         const uint32_t bin = j.touched[i];
-        const u64 hi = (u64)(0xFFFFFFFFu - j.hist[bin]), lo = j.ord2id[bin];
+        // (the count is taken with an exchange that leaves zero behind: self-cleaned pool, mgpu_ctx)
+        const u64 hi = (u64)(0xFFFFFFFFu - atomicExch((uint32_t *)j.hist + bin, 0u)), lo = j.ord2id[bin];
         j.key_hi[i] = hi; j.key_lo[i] = lo;
         a |= hi; b |= lo; na |= ~hi; nb |= ~lo;
     }
@@ -1038,13 +1039,18 @@ __global__ __launch_bounds__(MG_BLOCK) void k_fkeys(const FkJob *jobs) {
 }
 
 // distinct facet ids among the hits (cardinality agg, metric-aggs.c:23-45,47-55): the touched bins
-struct CardJob { const uint32_t *ord2id; const uint32_t *touched; const uint32_t *ntouched; uint32_t *out_ids; uint32_t *out_n; };
+struct CardJob { const uint32_t *ord2id; const uint32_t *touched; const uint32_t *ntouched; uint32_t *out_ids; uint32_t *out_n;
+                 uint32_t *clean_hist; };   // histogram to put back to zero (fields no facet job consumes), or NULL
 __global__ __launch_bounds__(MG_BLOCK) void k_card(const CardJob *jobs) {
     const CardJob j = jobs[blockIdx.y];
     const uint32_t n = *j.ntouched;
     if (blockIdx.x == 0 && threadIdx.x == 0) *j.out_n = n;
     for (uint32_t i = blockIdx.x * MG_BLOCK + threadIdx.x; i < n; i += gridDim.x * MG_BLOCK)
-        j.out_ids[i] = j.ord2id[j.touched[i]];
+    {
+        const uint32_t bin = j.touched[i];
+        j.out_ids[i] = j.ord2id[bin];
+        if (j.clean_hist) j.clean_hist[bin] = 0;
+    }
 }
 
 // ------------------------------------------------------------------ top-k selection
@@ -1300,11 +1306,12 @@ __device__ __forceinline__ void select_solo(const SelJob &job, const SelOut &out
 #define SOLO_LOAD(g) do { _Pragma("unroll") for (int u = 0; u < R; u++) { \
         const uint32_t i = (g) * SEL_SOLO_GROUP + u * NT + threadIdx.x; \
         rhi[u] = (i < M) ? job.key_hi[i] : 0; rlo[u] = (i < M) ? job.key_lo[i] : 0; } } while (0)
-    // facet keys derived here from the touched bins: (0xFFFFFFFF - count, bin ordinal), loads batched R deep
+    // facet keys derived here from the touched bins: (0xFFFFFFFF - count, bin ordinal), loads batched R deep.
+    // The count is taken with an exchange that leaves zero behind: the histogram pool cleans itself (mgpu_ctx).
 #define SOLO_GEN(g) do { uint32_t bins[R]; _Pragma("unroll") for (int u = 0; u < R; u++) { \
         const uint32_t i = (g) * SEL_SOLO_GROUP + u * NT + threadIdx.x; bins[u] = (i < M) ? job.gen_touched[i] : 0xFFFFFFFFu; } \
         _Pragma("unroll") for (int u = 0; u < R; u++) { const bool v = bins[u] != 0xFFFFFFFFu; \
-        rhi[u] = v ? (u64)(0xFFFFFFFFu - job.gen_hist[bins[u]]) : 0; rlo[u] = v ? (u64)bins[u] : 0; } } while (0)
+        rhi[u] = v ? (u64)(0xFFFFFFFFu - atomicExch((uint32_t *)job.gen_hist + bins[u], 0u)) : 0; rlo[u] = v ? (u64)bins[u] : 0; } } while (0)
     if (job.gen_touched) {
         // the varying bits of these keys are not known yet: OR / AND them over the list first.  A list
         // beyond the registers is written to key_hi/key_lo on the way, and read back from there after.
@@ -1681,7 +1688,8 @@ __global__ __launch_bounds__(MG_BLOCK) void k_select_first(const SelJob *jobs, c
         for (int u = 0; u < SEL_SMALL_CAP / MG_BLOCK; u++) {
             const uint32_t i = u * MG_BLOCK + threadIdx.x;
             if (i < M) {
-                s_fhi[i] = job.gen_touched ? (u64)(0xFFFFFFFFu - job.gen_hist[bins[u]]) : job.key_hi[i];
+                // (the count is taken with an exchange that leaves zero behind: self-cleaned pool, mgpu_ctx)
+                s_fhi[i] = job.gen_touched ? (u64)(0xFFFFFFFFu - atomicExch((uint32_t *)job.gen_hist + bins[u], 0u)) : job.key_hi[i];
                 s_flo[i] = job.gen_touched ? (u64)bins[u] : job.key_lo[i];
                 s_fix[i] = i;
             }
@@ -1916,6 +1924,18 @@ void mgk_select(hipStream_t st, const SelJob *jobs, const void *outs, uint32_t n
         hipLaunchKernelGGL(k_select_pass, dim3(gx, njobs), dim3(MG_BLOCK), 0, st, jobs, so, (int)SELMODE_HOST, L);
     hipLaunchKernelGGL((k_select_final<SEL_SMALL_CAP, 0>), dim3(njobs), dim3(MG_BLOCK), 0, st, jobs, so, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
     hipLaunchKernelGGL((k_select_final<SEL_BIG_CAP, SEL_SMALL_CAP + 1>), dim3(njobs), dim3(MG_BLOCK), 0, st, jobs, so, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
+}
+// test aid (MGPU_CHECK_CLEAN): *flag |= 1 when any word of the self-cleaned pool is not zero
+__global__ __launch_bounds__(MG_BLOCK) void k_check_zero(const uint4 *p, size_t n16, uint32_t *flag) {
+    uint32_t any = 0;
+    for (size_t i = (size_t)blockIdx.x * MG_BLOCK + threadIdx.x; i < n16; i += (size_t)gridDim.x * MG_BLOCK) {
+        const uint4 v = p[i];
+        any |= v.x | v.y | v.z | v.w;
+    }
+    if (any) atomicOr(flag, 1u);
+}
+void mgk_check_zero(hipStream_t st, const void *p, size_t bytes, uint32_t *flag) {
+    hipLaunchKernelGGL(k_check_zero, dim3(2048), dim3(MG_BLOCK), 0, st, (const uint4 *)p, bytes / 16, flag);
 }
 void mgk_row_op(hipStream_t st, const unsigned long long *a, const unsigned long long *b, unsigned long long *out,
                 uint32_t W, int op, unsigned long long *card) {

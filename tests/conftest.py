@@ -8,6 +8,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# every GPU batch of the test suite verifies that the self-cleaned histogram pool is all zero when it ends
+os.environ.setdefault("MGPU_CHECK_CLEAN", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
