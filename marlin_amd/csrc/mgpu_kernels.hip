@@ -1295,7 +1295,7 @@ template <int NT>
 __device__ __forceinline__ void select_solo(const SelJob &job, const SelOut &out, uint32_t M, u64 mhi, u64 mlo, uint32_t midx,
                                             uint32_t *hist, uint32_t *s_scan, uint32_t *s_pcur, uint32_t *s_runs,
                                             uint32_t *s_misc /* >= 6 */, u64 *s_fhi, u64 *s_flo, uint32_t *s_fix, uint32_t *s_fcnt,
-                                            u64 *s_red /* >= 4 * NT / 64 */) {
+                                            u64 *s_red /* >= 4 * NT / 64 */, bool pregen = false) {
     DBG_T(ts0);
     constexpr int DS = (NT == MG_BLOCK) ? 4 : 17;        // phase-clock slots: small / big workgroup variant
     constexpr int R = SEL_SOLO_REG * SEL_ITEMS;
@@ -1312,7 +1312,7 @@ __device__ __forceinline__ void select_solo(const SelJob &job, const SelOut &out
         const uint32_t i = (g) * SEL_SOLO_GROUP + u * NT + threadIdx.x; bins[u] = (i < M) ? job.gen_touched[i] : 0xFFFFFFFFu; } \
         _Pragma("unroll") for (int u = 0; u < R; u++) { const bool v = bins[u] != 0xFFFFFFFFu; \
         rhi[u] = v ? (u64)(0xFFFFFFFFu - atomicExch((uint32_t *)job.gen_hist + bins[u], 0u)) : 0; rlo[u] = v ? (u64)bins[u] : 0; } } while (0)
-    if (job.gen_touched) {
+    if (job.gen_touched && !pregen) {
         // the varying bits of these keys are not known yet: OR / AND them over the list first.  A list
         // beyond the registers is written to key_hi/key_lo on the way, and read back from there after.
         u64 a = 0, b = 0, na = 0, nb = 0;
@@ -1724,6 +1724,31 @@ __global__ __launch_bounds__(MG_BLOCK) void k_select_first(const SelJob *jobs, c
     __syncthreads();
     if (s_misc[0] != 0xFFFFFFFFu && threadIdx.x < want) L.items[0][s_misc[0] + threadIdx.x] = make_uint2(ji, threadIdx.x);
 }
+// Derived facet keys of the mid-size lists: (0xFFFFFFFF - count, bin ordinal) written to key_hi / key_lo by
+// SEL_FKM_WG workgroups per list (the one big workgroup of k_select_mid would spend most of its time in
+// these gathers), varying bits accumulated into the job's mask words as k_fkeys does.
+#define SEL_FKM_WG 16
+__global__ __launch_bounds__(MG_BLOCK) void k_fkeys_mid(const SelJob *jobs, SelLists L) {
+    const uint32_t n = *L.nmid;
+    const int lane = threadIdx.x & 63;
+    for (uint32_t w = blockIdx.y; w < n; w += gridDim.y) {
+        const SelJob job = jobs[L.mid[w]];
+        if (!job.gen_touched) continue;
+        const uint32_t M = *job.m_ptr;
+        u64 a = 0, b = 0, na = 0, nb = 0;
+        for (uint32_t i = blockIdx.x * MG_BLOCK + threadIdx.x; i < M; i += gridDim.x * MG_BLOCK) {
+            const uint32_t bin = job.gen_touched[i];
+            const u64 hi = (u64)(0xFFFFFFFFu - atomicExch((uint32_t *)job.gen_hist + bin, 0u)), lo = bin;
+            ((u64 *)job.key_hi)[i] = hi; ((u64 *)job.key_lo)[i] = lo;
+            a |= hi; b |= lo; na |= ~hi; nb |= ~lo;
+        }
+        a = wave_or64(a); b = wave_or64(b); na = wave_or64(na); nb = wave_or64(nb);
+        if (lane == 0 && (a | b | na | nb)) {
+            u64 *mk = (u64 *)job.mask;
+            atomicOr(&mk[0], na); atomicOr(&mk[1], nb); atomicOr(&mk[2], a); atomicOr(&mk[3], b);
+        }
+    }
+}
 // The lists k_select_first found too long for 256 threads but short enough for one big workgroup:
 // select_solo again, four times the lanes.  A small grid strides over the list.
 __global__ __launch_bounds__(SEL_MID_BLOCK) void k_select_mid(const SelJob *jobs, const SelOut *outs, SelLists L) {
@@ -1739,7 +1764,8 @@ __global__ __launch_bounds__(SEL_MID_BLOCK) void k_select_mid(const SelJob *jobs
         const uint32_t M = *job.m_ptr;
         u64 mhi, mlo; uint32_t midx;
         job_masks(job, M, mhi, mlo, midx);
-        select_solo<SEL_MID_BLOCK>(job, outs[ji], M, mhi, mlo, midx, hist, s_scan, s_pcur, s_runs, s_misc, s_fhi, s_flo, s_fix, s_fcnt, s_red);
+        // (derived facet keys of these long lists were written out by k_fkeys_mid, many workgroups per list)
+        select_solo<SEL_MID_BLOCK>(job, outs[ji], M, mhi, mlo, midx, hist, s_scan, s_pcur, s_runs, s_misc, s_fhi, s_flo, s_fix, s_fcnt, s_red, true);
         __syncthreads();
     }
 }
@@ -1903,8 +1929,10 @@ void mgk_select(hipStream_t st, const SelJob *jobs, const void *outs, uint32_t n
         // first go: exactly one workgroup per job, no idle ones ...
         hipLaunchKernelGGL(k_select_first, dim3(njobs), dim3(MG_BLOCK), 0, st, jobs, so, L);
         if (max_m <= MG_SEL_SMALL) return;                                 // no job of this batch can end up on a list
-        if (max_m > SEL_SOLO_CHUNKS * SEL_CHUNK)
+        if (max_m > SEL_SOLO_CHUNKS * SEL_CHUNK) {
+            hipLaunchKernelGGL(k_fkeys_mid, dim3(SEL_FKM_WG, njobs < 128 ? njobs : 128), dim3(MG_BLOCK), 0, st, jobs, L);
             hipLaunchKernelGGL(k_select_mid, dim3(njobs < 256 ? njobs : 256), dim3(SEL_MID_BLOCK), 0, st, jobs, so, L);
+        }
         // ... then the wide launches over exactly the workgroups the long lists asked for, and the
         // stand-alone sorts for the jobs on the final list
         if (cap_items) {
