@@ -73,8 +73,8 @@ def make_queries(lib, n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=24)
     ap.add_argument("--docs", type=int, default=10_000_000)
     ap.add_argument("--batch", type=int, default=128, help="queries per step and GPU")
     ap.add_argument("--cpu-queries", type=int, default=4)
