@@ -19,6 +19,11 @@ eng = GpuEngine(ix, device=0)
 lib.msq_set_plan_threads(16)
 NB = int(os.environ.get("PROBE_BATCH", "32"))
 pool = [ix.query(j) for j in bench.make_queries(lib, NB)]
+only = os.environ.get("PROBE_FACET_ONLY")        # count facets of one field only (index into cat, hc)
+if only is not None:
+    for pq in pool:
+        for f in range(2):
+            pq.q.contents.cfg.facet_enabled[f] = 1 if f == int(only) else 0
 prep = eng.prepare(pool[:NB])
 for _ in range(3):
     eng.free_raw(eng.execute_prepared(prep))
