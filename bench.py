@@ -190,6 +190,7 @@ def main():
 
         def worker(t):
             try:
+                torch.cuda.set_device(local_rank)        # torch's current device is per thread
                 for i in range(t, count, F):
                     hits[t] += run_step(first + i, t, i)
             except BaseException as e:          # surface failures instead of hanging the other thread

@@ -21,6 +21,7 @@ class ShardGather:
         self.slot_b = lib.m_slot_bytes(*self.shape)
         n = nq * local_shards * self.slot_b
         self.on_gpu = device is not None and str(device).startswith("cuda")
+        self.device = torch.device(device) if self.on_gpu else None
         self.host_send = torch.empty(n, dtype=torch.uint8)
         self.host_recv = torch.empty(world * n, dtype=torch.uint8)
         if self.on_gpu:
@@ -41,9 +42,12 @@ class ShardGather:
         the ranks with no further communication.  The caller frees the array with free()."""
         lib = self.lib
         if self.on_gpu:
+            # torch's current device is per thread and the callers are worker threads: name the device
+            self.torch.cuda.set_device(self.device)
+            stream = self.torch.cuda.current_stream(self.device)
             # the previous call's async copy out of host_send must have run before it is overwritten;
             # wait on torch's stream only (a device-wide sync would stall the other contexts' batches)
-            self.torch.cuda.current_stream().synchronize()
+            stream.synchronize()
         lib.m_slot_pack_batch(outs, self.nq * self.local, *self.shape, self.host_send.data_ptr())
         if self.on_gpu:
             self.send.copy_(self.host_send, non_blocking=True)
@@ -51,7 +55,7 @@ class ShardGather:
             if self.rank != 0 and not share:
                 return None
             self.host_recv.copy_(self.recv, non_blocking=True)
-            self.torch.cuda.current_stream().synchronize()
+            stream.synchronize()
         else:
             self.dist.all_gather_into_tensor(self.host_recv, self.host_send)
             if self.rank != 0 and not share:
