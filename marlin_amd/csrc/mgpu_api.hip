@@ -60,6 +60,7 @@ struct mgpu_shard {
     std::vector<uint64_t> post_off;     // sparse CSR offsets (per pid)
     std::vector<uint32_t> post_card;    // docs per posting (bounds the hit count of a plan)
     std::vector<uint32_t> post_winbase; // per pid: base into post_win, or ~0 (dense, empty or short posting)
+    uint32_t fac_single = 0;            // bit f: every document has <= 1 value in facet field f, and every facet section is staged whole by the rank kernel
     uint64_t np_n[MGPU_MAX_FIELDS];
     double avg_dw;                      // mean docword entries per doc
     double avg_fv[MGPU_MAX_FIELDS];     // mean facet values per doc
@@ -260,11 +261,13 @@ extern "C" int mgpu_shard_create(int device, const mgpu_shard_desc_t *d, mgpu_sh
             uint32_t S = 512, acc = 0;
             for (uint32_t c = 1; c <= 4; c++) { acc += hist[c]; if ((uint64_t)acc * 10 >= (uint64_t)(N - 1) * 9) { S = c * 128; break; } }
             std::vector<uint32_t> rec((size_t)N * (S / 4), 0);
+            bool all_staged = d->num_facets > 0;
             for (uint32_t doc = 1; doc < N; doc++) {
                 uint32_t *r = rec.data() + (size_t)doc * (S / 4);
                 const uint32_t nwords = dw_off[doc + 1] - dw_off[doc];
                 uint32_t fb = facet_bytes(doc);
                 const bool facets_in = d->num_facets > 0 && hdr + fb <= S / 2;
+                if (!facets_in || fb > 4 * MG_PCAP) all_staged = false;
                 if (!facets_in) fb = 0;
                 const uint32_t ws = (hdr + fb) / 8;
                 uint32_t nin = (S - (hdr + fb)) / 8;
@@ -285,6 +288,12 @@ extern "C" int mgpu_shard_create(int device, const mgpu_shard_desc_t *d, mgpu_sh
                 for (uint32_t j = 0; j < nin; j++) { r[2 * (ws + j)] = dw[dw_off[doc] + j].x; r[2 * (ws + j) + 1] = dw[dw_off[doc] + j].y; }
             }
             if ((rc = upload(s, rec, &sd.rec))) { mgpu_shard_destroy(s); return rc; }
+            if (all_staged)
+                for (int f = 0; f < d->num_facets; f++) {
+                    bool single = true;
+                    for (uint32_t doc = 1; doc < N && single; doc++) single = fa_off[f][doc + 1] - fa_off[f][doc] <= 1;
+                    if (single) s->fac_single |= 1u << f;
+                }
             sd.rec_stride = S; sd.rec_nnum = (uint32_t)nnum_in;
             s->rec_stride = S;
         }
@@ -767,7 +776,9 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
         o.aggpart = nz.take((size_t)q.nproc_blocks * std::max(1, p.num_aggs) * sizeof(AggPart));
         for (int j = 0; j < h.nfac; j++) {
             int f = h.fac_field[j];
-            o.fkhi[f] = nz.take((size_t)sd.fa_nord[f] * 8); o.fklo[f] = nz.take((size_t)sd.fa_nord[f] * 8);
+            // (a directly counted field lists one entry per hit instead of one per distinct value)
+            const size_t nkeys = ((sh->fac_single >> f) & 1u) ? std::max<size_t>(sd.fa_nord[f], q.hit_cap) : sd.fa_nord[f];
+            o.fkhi[f] = nz.take(nkeys * 8); o.fklo[f] = nz.take(nkeys * 8);
             max_fk = std::max(max_fk, sd.fa_nord[f]);
         }
         h.ncard = 0;
@@ -891,9 +902,22 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
             items.push_back(it);
         }
     }
+    // need_keys: the rank kernel has nothing to do when no hits are requested
+    for (int i = 0; i < n; i++) if (!sqh[i].k) sqd[i].do_rank = -1;
+    // facet counting rides on the rank kernel's record visit whenever that kernel reads the records
+    {
+        const bool fuse = !getenv("MGPU_NO_FUSED_FACETS");
+        for (int i = 0; i < n; i++) {
+            SqDev &q = sqd[i];
+            const bool reads_records = q.do_rank == 1 || (q.do_rank == 0 && q.rank_by >= 0 && (uint32_t)q.rank_by < q.sh.rec_nnum);
+            q.fac_in_rank = (fuse && q.hist_mask && reads_records) ? 1 : 0;
+        }
+    }
+
     // facet keys: when every facet list of the batch fits the one-workgroup selections, those derive
     // the keys from the touched bins themselves and k_fkeys is not launched
     const bool fuse_fk = max_fac_nord <= MG_SEL_MID_KEYS && max_fac_k <= MG_SEL_SOLO_K && !getenv("MGPU_NO_FUSED_FKEYS");
+    const bool use_fdirect = !getenv("MGPU_NO_DIRECT_FACETS");
     seljobs.resize(seloff.size()); selouts.resize(seloff.size());
     for (size_t j = 0; j < seloff.size(); j++) {
         const SelOff &so = seloff[j]; const JobFix &jf = jobfix[j];
@@ -923,6 +947,15 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
             fj.andor = (u64 *)(Z + so.andor);
             if (fuse_fk) { sj.gen_touched = fj.touched; sj.gen_hist = fj.hist; sj.gen_ord2id = fj.ord2id; }
             else fkjobs.push_back(fj);
+            // a sparse field (too many bins for an LDS histogram) of single-valued documents: counted straight from
+            // the rank kernel, the per-hit ordinals are the touched list (SqDev::fdirect_mask)
+            bool card_on_f = false;
+            for (int a = 0; a < q.num_aggs; a++) card_on_f |= q.agg_type[a] == MGPU_A_CARDINALITY && q.agg_field[a] == f;
+            if (fuse_fk && use_fdirect && q.fac_in_rank && ((shards[jf.sq]->fac_single >> f) & 1u) && q.sh.fa_nord[f] > MG_LDS_HIST &&
+                !card_on_f && q.hit_cap <= MG_SEL_MID_KEYS) {
+                q.fdirect_mask |= 1u << f;
+                sj.gen_touched = q.fac_ord[f]; sj.m_ptr = q.num_hits;
+            }
         }
     }
     for (int i = 0; i < n; i++) {
@@ -939,18 +972,6 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
             cardjobs.push_back(cj);
         }
     }
-    // need_keys: the rank kernel has nothing to do when no hits are requested
-    for (int i = 0; i < n; i++) if (!sqh[i].k) sqd[i].do_rank = -1;
-    // facet counting rides on the rank kernel's record visit whenever that kernel reads the records
-    {
-        const bool fuse = !getenv("MGPU_NO_FUSED_FACETS");
-        for (int i = 0; i < n; i++) {
-            SqDev &q = sqd[i];
-            const bool reads_records = q.do_rank == 1 || (q.do_rank == 0 && q.rank_by >= 0 && (uint32_t)q.rank_by < q.sh.rec_nnum);
-            q.fac_in_rank = (fuse && q.hist_mask && reads_records) ? 1 : 0;
-        }
-    }
-
     // staging copy
     memcpy(c->pin + up_sq, sqd.data(), sizeof(SqDev) * n);
     if (!blob.empty()) memcpy(c->pin + up_blob, blob.data(), blob.size() * 4);

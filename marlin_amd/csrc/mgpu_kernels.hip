@@ -621,7 +621,7 @@ __global__ __launch_bounds__(MG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
         const KeyLayout kl = load_key_layout(sp);
         const double *col = sp->sh.num_col[rb >= 0 ? rb : 0];
         const int fac_here = sp->fac_in_rank;
-        const uint32_t fac_mask = sp->hist_mask;
+        const uint32_t fac_mask = sp->hist_mask, fdirect = sp->fdirect_mask;
         const int nfac = sp->sh.num_facets;
         if (do_rank < 0) continue;                   // no hits requested: nobody reads the keys
         const uint32_t M = *p_num_hits;
@@ -774,6 +774,8 @@ __global__ __launch_bounds__(MG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                             pos += 1 + cnt;
                         } else staged_ok = false;
                         if ((hist_mask >> f) & 1u) sp->fac_ord[f][t] = code;
+                        // directly counted field: one fire-and-forget atomic, nothing waits for it
+                        if (((fdirect >> f) & 1u) && code < MG_FAC_LOOKUP) atomicAdd(&sp->hist[f][code], 1u);
                     }
                 }
                 s_np[tid] = 0;
@@ -914,7 +916,7 @@ __global__ __launch_bounds__(MG_BLOCK) void k_docproc(const SqDev *sqs, const ui
         const uint32_t *rec = sq.sh.rec;
         const uint32_t nnum_in = sq.sh.rec_nnum;
         for (int f = 0; f < sq.sh.num_facets; f++) {
-            if (!((sq.hist_mask >> f) & 1u)) continue;
+            if (!((sq.hist_mask >> f) & 1u) || ((sq.fdirect_mask >> f) & 1u)) continue;
             const uint32_t nord = sq.sh.fa_nord[f];
             const uint32_t *off = sq.sh.fa_off[f];
             const uint32_t *ord = sq.sh.fa_ord[f];
@@ -1189,7 +1191,7 @@ __device__ __forceinline__ void sel_sort_emit(const SelJob &job, const SelOut &o
     }
     const uint32_t kk = job.k < n ? job.k : n;
     for (uint32_t i = threadIdx.x; i < kk; i += NT) {
-        if (job.skip_ones && s_hi[i] == ~0ull) continue;
+        if (job.skip_ones && s_hi[i] >= 0xFFFFFFFFull) continue;        // facet entries with a zero count (see SqDev::fdirect_mask)
         // derived facet keys carry the bin ordinal (same order as the facet id: ordinals are ranks of
         // the sorted ids); the id itself is looked up for the k winners only
         out.out_hi[i] = s_hi[i]; out.out_lo[i] = job.gen_touched ? (u64)job.gen_ord2id[s_lo[i]] : s_lo[i];
@@ -1310,8 +1312,8 @@ __device__ __forceinline__ void select_solo(const SelJob &job, const SelOut &out
     // The count is taken with an exchange that leaves zero behind: the histogram pool cleans itself (mgpu_ctx).
 #define SOLO_GEN(g) do { uint32_t bins[R]; _Pragma("unroll") for (int u = 0; u < R; u++) { \
         const uint32_t i = (g) * SEL_SOLO_GROUP + u * NT + threadIdx.x; bins[u] = (i < M) ? job.gen_touched[i] : 0xFFFFFFFFu; } \
-        _Pragma("unroll") for (int u = 0; u < R; u++) { const bool v = bins[u] != 0xFFFFFFFFu; \
-        rhi[u] = v ? (u64)(0xFFFFFFFFu - atomicExch((uint32_t *)job.gen_hist + bins[u], 0u)) : 0; rlo[u] = v ? (u64)bins[u] : 0; } } while (0)
+        _Pragma("unroll") for (int u = 0; u < R; u++) { const bool v = bins[u] < MG_FAC_LOOKUP; /* a bin, not "no value" */ \
+        rhi[u] = v ? (u64)(0xFFFFFFFFu - atomicExch((uint32_t *)job.gen_hist + bins[u], 0u)) : 0xFFFFFFFFull; rlo[u] = (u64)bins[u]; } } while (0)
     if (job.gen_touched && !pregen) {
         // the varying bits of these keys are not known yet: OR / AND them over the list first.  A list
         // beyond the registers is written to key_hi/key_lo on the way, and read back from there after.
@@ -1689,7 +1691,8 @@ __global__ __launch_bounds__(MG_BLOCK) void k_select_first(const SelJob *jobs, c
             const uint32_t i = u * MG_BLOCK + threadIdx.x;
             if (i < M) {
                 // (the count is taken with an exchange that leaves zero behind: self-cleaned pool, mgpu_ctx)
-                s_fhi[i] = job.gen_touched ? (u64)(0xFFFFFFFFu - atomicExch((uint32_t *)job.gen_hist + bins[u], 0u)) : job.key_hi[i];
+                s_fhi[i] = !job.gen_touched ? job.key_hi[i]
+                         : bins[u] >= MG_FAC_LOOKUP ? 0xFFFFFFFFull : (u64)(0xFFFFFFFFu - atomicExch((uint32_t *)job.gen_hist + bins[u], 0u));
                 s_flo[i] = job.gen_touched ? (u64)bins[u] : job.key_lo[i];
                 s_fix[i] = i;
             }
@@ -1738,7 +1741,7 @@ __global__ __launch_bounds__(MG_BLOCK) void k_fkeys_mid(const SelJob *jobs, SelL
         u64 a = 0, b = 0, na = 0, nb = 0;
         for (uint32_t i = blockIdx.x * MG_BLOCK + threadIdx.x; i < M; i += gridDim.x * MG_BLOCK) {
             const uint32_t bin = job.gen_touched[i];
-            const u64 hi = (u64)(0xFFFFFFFFu - atomicExch((uint32_t *)job.gen_hist + bin, 0u)), lo = bin;
+            const u64 hi = bin >= MG_FAC_LOOKUP ? 0xFFFFFFFFull : (u64)(0xFFFFFFFFu - atomicExch((uint32_t *)job.gen_hist + bin, 0u)), lo = bin;
             ((u64 *)job.key_hi)[i] = hi; ((u64 *)job.key_lo)[i] = lo;
             a |= hi; b |= lo; na |= ~hi; nb |= ~lo;
         }

@@ -127,6 +127,11 @@ struct SqDev {
     uint32_t *ovf_list;              // [N] hit indices whose position lists overflowed
     // ---- doc processing (facets + aggs) ----
     uint32_t hist_mask;              // bit f: histogram field f
+    // bit f: field f is counted straight from the rank kernel (fire-and-forget atomics on hist[f], one per hit:
+    // every document has at most one value and its facet section is staged); the hit's ordinals in fac_ord[f]
+    // then ARE the list of touched bins (with repeats, which the exchange in the key derivation turns into
+    // zero counts), k_docproc skips the field and no touched list is built
+    uint32_t fdirect_mask;
     int32_t  fac_in_rank;            // the rank kernel leaves every hit's facet ordinals in fac_ord while it holds the records
     uint32_t *fac_ord[MGPU_MAX_FIELDS];   // [hit_cap] per histogram field: the hit's ordinal, MG_FAC_NONE, or MG_FAC_LOOKUP
     uint32_t *hist[MGPU_MAX_FIELDS]; // [fa_nord[f]] zeroed per query

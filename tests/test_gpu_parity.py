@@ -89,6 +89,37 @@ def test_facets_counted_without_the_rank_kernels_ordinals(dg, monkeypatch):
         compare_results(g, orc_py.search(ix, pq, flags=3), ctx=pq.jq)
 
 
+def test_sparse_facets_through_touched_lists(monkeypatch):
+    """a sparse single-valued facet field counted by k_docproc with first-touch lists (the path of fields that
+    also feed a cardinality aggregation, or whose documents can hold several values) instead of straight
+    from the rank kernel"""
+    import test_gpu_scale as sc
+    lib = sc.ffi.load()
+    shards = [lib.msynth_zipf(40_000, 2048, 20_000, 5, s, 2) for s in range(2)]
+    ix = Index.from_shards({}, shards, ["str"], ["num", "price"], ["flag"], ["cat", "hc"])
+    buf = sc.C.create_string_buffer(16)
+    def zw(r):
+        lib.msynth_zipf_word(2048, 5, r, buf)
+        return buf.value.decode()
+    qs = [{"q": zw(0), "maxFacetResults": 10}, {"q": zw(3) + " " + zw(40), "maxFacetResults": 5},
+          {"q": zw(1), "aggs": {"c": {"cardinality": {"field": "hc"}}}, "maxFacetResults": 8}]
+    results = []
+    for env in (None, "1"):
+        if env:
+            monkeypatch.setenv("MGPU_NO_DIRECT_FACETS", env)
+        eng = GpuEngine(ix)
+        try:
+            pqs = [ix.query(dict(q, fullScan=True)) for q in qs]
+            got = eng.search(pqs, capture=3)
+            for pq, g in zip(pqs, got):
+                compare_results(g, orc_py.search(ix, pq, flags=3), ctx=pq.jq)
+            results.append([(g["totalHits"], g["facets"]) for g in got])
+        finally:
+            eng.close()
+    ix.close()
+    assert results[0] == results[1] and results[0][0][0] > 0
+
+
 def test_many_facet_results_need_the_big_final_sort(dg):
     """2 * maxFacetResults above the one-workgroup selection's k: keys by k_fkeys, wide passes + big sort"""
     ix, eng = dg
