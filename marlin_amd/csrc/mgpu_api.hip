@@ -1113,9 +1113,17 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
         c->stage_bytes[1] += h.scatter_docs * 4;
         c->stage_bytes[2] += h.formula_rows * B + h.sparse_docs * 4 + B + 4 * M;
         if (h.k) c->stage_bytes[3] += M * (uint64_t)(4 + 16 + 8.0 * sh->avg_dw + (p.rank_by >= 0 ? 8 : 0) + 16);
+        // facet work that rides on the rank kernel's record visit: the ordinal it leaves per hit and field (4 B
+        // written), and for the directly counted fields the histogram update (8 B read-modify-write)
+        if (q.fac_in_rank)
+            for (int f = 0; f < q.sh.num_facets; f++) if ((q.hist_mask >> f) & 1u)
+                c->stage_bytes[3] += M * (uint64_t)(4 + (((q.fdirect_mask >> f) & 1u) ? 8 : 0));
         {
             double per = 0;
-            for (int f = 0; f < q.sh.num_facets; f++) if ((q.hist_mask >> f) & 1u) per += 4 + 8 + 4.0 * sh->avg_fv[f];
+            for (int f = 0; f < q.sh.num_facets; f++) if ((q.hist_mask >> f) & 1u) {
+                if ((q.fdirect_mask >> f) & 1u) continue;                 // counted in the rank stage
+                per += q.fac_in_rank ? 4 + 4 : 4 + 8 + 4.0 * sh->avg_fv[f];       // ordinal + bin, or docid + record header + values
+            }
             int na = 0; for (int a = 0; a < p.num_aggs; a++) if (p.agg_type[a] != MGPU_A_CARDINALITY) na++;
             per += na * (4 + 8);
             c->stage_bytes[4] += (uint64_t)(M * per);
