@@ -85,3 +85,26 @@ def test_sparse_postings_over_windows_and_term_groups(zipf):
     for pq, g in zip(pqs, got):
         compare_results(g, orc_py.search(ix, pq, flags=3), ctx=pq.jq)
     assert any(g["totalHits"] > 0 for g in got)
+
+
+def test_more_sparse_lists_than_one_chunk():
+    """a four-letter prefix shared by 900 words: one term unions 900 sparse postings (600 long ones that go
+    through the window index, 300 short ones scanned whole), more than the 256 lists a formula workgroup
+    ranges in one go, on a shard of two windows"""
+    docs = []
+    for i in range(40_000):
+        w1 = "abcd%03dx" % (i % 600)
+        extra = ("abcd%03dy" % (600 + i % 300)) if i % 13 == 0 else "pad"
+        docs.append({"id": i, "str": "%s %s w%d" % (w1, extra, i % 7), "num": i % 1000})
+    ix = Index({"indexedFields": ["str", "num"], "facetFields": [], "hitsPerPage": 30}, num_shards=1).add_documents(docs)
+    eng = GpuEngine(ix)
+    try:
+        qs = [{"q": "abcd"}, {"q": "w3 abcd", "rankBy": {"num": "desc"}}, {"q": "abcd1", "hitsPerPage": 50},
+              {"q": "w5 abcd", "filter": {"num": {"$lt": 500}}}]
+        pqs = [ix.query(dict(jq, fullScan=True)) for jq in qs]
+        got = eng.search(pqs, capture=3)
+        for pq, g in zip(pqs, got):
+            compare_results(g, orc_py.search(ix, pq, flags=3), ctx=pq.jq)
+        assert got[0]["totalHits"] > 30_000 and got[3]["totalHits"] > 0
+    finally:
+        eng.close(); ix.close()
