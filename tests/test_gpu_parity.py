@@ -102,7 +102,10 @@ def test_sparse_facets_through_touched_lists(monkeypatch):
         lib.msynth_zipf_word(2048, 5, r, buf)
         return buf.value.decode()
     qs = [{"q": zw(0), "maxFacetResults": 10}, {"q": zw(3) + " " + zw(40), "maxFacetResults": 5},
-          {"q": zw(1), "aggs": {"c": {"cardinality": {"field": "hc"}}}, "maxFacetResults": 8}]
+          {"q": zw(1), "aggs": {"c": {"cardinality": {"field": "hc"}}}, "maxFacetResults": 8},
+          {"q": "", "sortBy": {"num": "asc"}, "maxFacetResults": 6},       # no words: the rank kernel still reads the records
+          {"q": "", "maxFacetResults": 6},                                   # ... and here it does not: k_docproc looks up
+          {"q": zw(2), "hitsPerPage": 0, "maxHits": 0, "maxFacetResults": 4}]   # facets only
     results = []
     for env in (None, "1"):
         if env:
