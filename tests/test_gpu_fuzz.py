@@ -1,0 +1,19 @@
+"""Seeded randomised differential test: generated queries (typos, prefixes, 0-4 words, filters, sort / rankBy,
+pages, facets with small and large cut-offs, aggregations incl. cardinality, facets-only) on the reference's
+test corpus (multi-valued facets) and on a two-shard Zipf corpus with a sparse 20000-value facet field; the GPU
+path must equal the CPU oracle per shard (bitmap words, every rank record, top-2N, facets, aggs) and merged.
+tools/fuzz_parity.py runs the same generator for as long as one likes (3 x 3000 queries were clean)."""
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+import fuzz_parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", [3, 2024])
+def test_generated_queries_match_the_oracle(seed):
+    assert fuzz_parity.main(150, seed) == 0

@@ -77,18 +77,53 @@ def compare_results(gpu, orc, ctx=""):
     gk = [rank_key(r) for r in gpu["ranks"]]
     ok = [rank_key(r) for r in orc["ranks"]]
     assert gk == ok, ctx
+    # (a key that equals the LAST key a shard kept may tie with documents that shard cut: tie class, any member)
+    cut_keys = set()
+    for gs in gpu["_shards"]:
+        if gs["num_hits"] > gs["rank_count"] and gs["ranks"]:
+            cut_keys.add(tuple(gs["ranks"][-1][1:]))
     for i, (a, b) in enumerate(zip(gpu["ranks"], orc["ranks"])):
-        if gk.count(gk[i]) == 1 and not _boundary_tie(gpu, i):
+        if gk.count(gk[i]) == 1 and not _boundary_tie(gpu, i) and tuple(gk[i]) not in cut_keys:
             assert (a["shard"], a["docid"]) == (b["shard"], b["docid"]), (ctx, i)
-    # facets: same counts everywhere; same ids above the cut-off count
+    # per-shard facet lists (top 2N): same counts everywhere; same ids above the cut-off count.  Which of the
+    # ids that TIE at the cut-off count a shard keeps is the reference's quickselect residue (DESIGN.md "ties").
+    exact_lists = {}
+    for s, (gs, os_) in enumerate(zip(gpu["_shards"], orc["_shards"])):
+        assert gs["facets"].keys() == os_["facets"].keys(), (ctx, s)
+        for f in gs["facets"]:
+            ga = sorted(((c, i) for i, c in gs["facets"][f]), key=lambda t: (-t[0], t[1]))
+            oa = sorted(((c, i) for i, c in os_["facets"][f]), key=lambda t: (-t[0], t[1]))
+            assert [c for c, _ in ga] == [c for c, _ in oa], (ctx, s, "facet counts", f)
+            if ga:
+                cut = ga[-1][0]
+                assert [e for e in ga if e[0] > cut] == [e for e in oa if e[0] > cut], (ctx, s, "facet ids", f)
+            exact_lists[f] = exact_lists.get(f, True) and ga == oa
+    # merged facets: same counts everywhere; same ids above the cut-off count.  With several shards the sums
+    # themselves depend on the shards' tie choices, so the merged lists are compared only when no shard's list
+    # differed in its tied tail.
     gf, of = facets_canonical(gpu), facets_canonical(orc)
     assert gf.keys() == of.keys(), ctx
-    for k in gf:
+    names = list(gf.keys())
+    for n, k in enumerate(names):
+        fields = [f for f in exact_lists]
+        if len(gpu["_shards"]) > 1 and fields and not all(exact_lists.values()):
+            continue
         assert [c for c, _ in gf[k]] == [c for c, _ in of[k]], (ctx, k)
         if gf[k]:
             cut = gf[k][-1][0]
             assert [e for e in gf[k] if e[0] > cut] == [e for e in of[k] if e[0] > cut], (ctx, k)
-    assert gpu.get("aggs") == orc.get("aggs"), ctx
+    assert _same(gpu.get("aggs"), orc.get("aggs")), ctx
+
+
+def _same(a, b):
+    """equality that treats NaN == NaN (avg of an empty hit set)"""
+    if isinstance(a, dict) and isinstance(b, dict):
+        return a.keys() == b.keys() and all(_same(a[k], b[k]) for k in a)
+    if isinstance(a, (list, tuple)) and isinstance(b, (list, tuple)):
+        return len(a) == len(b) and all(_same(x, y) for x, y in zip(a, b))
+    if isinstance(a, float) and isinstance(b, float) and a != a and b != b:
+        return True
+    return a == b
 
 
 def _boundary_tie(res, i):
