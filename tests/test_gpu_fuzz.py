@@ -1,8 +1,9 @@
 """Seeded randomised differential test: generated queries (typos, prefixes, 0-4 words, filters, sort / rankBy,
 pages, facets with small and large cut-offs, aggregations incl. cardinality, facets-only) on the reference's
-test corpus (multi-valued facets) and on a two-shard Zipf corpus with a sparse 20000-value facet field; the GPU
+test corpus (multi-valued facets), on a two-shard Zipf corpus with a sparse 20000-value facet field and on a
+four-shard corpus with repeated words, floats and custom rank rule sets; the GPU
 path must equal the CPU oracle per shard (bitmap words, every rank record, top-2N, facets, aggs) and merged.
-tools/fuzz_parity.py runs the same generator for as long as one likes (3 x 3000 queries were clean)."""
+tools/fuzz_parity.py runs the same generator for as long as one likes (20000 queries were clean)."""
 import os
 import sys
 

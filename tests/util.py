@@ -24,8 +24,11 @@ def jpath(obj, path):
     return cur
 
 
-def rank_key(r):
-    return (r["typos"], r["proximity"], r["field"], r["position"], r["exact"], r["compare"])
+RANK_FIELDS = ("typos", "proximity", "field", "position", "exact", "compare")
+
+
+def rank_key(r, fields=RANK_FIELDS):
+    return tuple(r[f] for f in fields)
 
 
 def facets_canonical(res):
@@ -53,12 +56,13 @@ def datagen_index(rend=10000, seed=12345):
     return ix, fcount
 
 
-def compare_results(gpu, orc, ctx=""):
+def compare_results(gpu, orc, ctx="", key_fields=RANK_FIELDS):
     """GPU result vs oracle result for one query (both assembled with capture flags 3).
 
     Exact where the reference defines the answer; tie-class aware where it does not
     (DESIGN.md "ties"): equal rank keys may carry different docids, facets of equal count at
-    the cut may differ."""
+    the cut may differ.  key_fields: the rank fields the query orders by (a custom rankAlgorithm leaves the
+    others out of the order, so documents that differ only in those form one tie class)."""
     assert gpu["totalHits"] == orc["totalHits"], ctx
     assert gpu["numHits"] == orc["numHits"], ctx
     # stage level: bitmap words and every per-document rank record
@@ -74,14 +78,15 @@ def compare_results(gpu, orc, ctx=""):
         for a, b in zip(gs["aggs"], os_["aggs"]):
             assert a == b, (ctx, s, "agg", a, b)
     # merged order: identical key sequence; docids identical wherever the key is unique
-    gk = [rank_key(r) for r in gpu["ranks"]]
-    ok = [rank_key(r) for r in orc["ranks"]]
+    gk = [rank_key(r, key_fields) for r in gpu["ranks"]]
+    ok = [rank_key(r, key_fields) for r in orc["ranks"]]
     assert gk == ok, ctx
     # (a key that equals the LAST key a shard kept may tie with documents that shard cut: tie class, any member)
     cut_keys = set()
     for gs in gpu["_shards"]:
         if gs["num_hits"] > gs["rank_count"] and gs["ranks"]:
-            cut_keys.add(tuple(gs["ranks"][-1][1:]))
+            last = dict(zip(("docid",) + RANK_FIELDS, gs["ranks"][-1]))
+            cut_keys.add(rank_key(last, key_fields))
     for i, (a, b) in enumerate(zip(gpu["ranks"], orc["ranks"])):
         if gk.count(gk[i]) == 1 and not _boundary_tie(gpu, i) and tuple(gk[i]) not in cut_keys:
             assert (a["shard"], a["docid"]) == (b["shard"], b["docid"]), (ctx, i)

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from marlin_amd import GpuEngine, Index, QueryError, ffi
 from oracle import orc_py
-from util import compare_results, datagen_index
+from util import RANK_FIELDS, compare_results, datagen_index
 
 
 def mutate(rng, w):
@@ -85,20 +85,79 @@ def zipf_queries(rng, lib, n, vocab, seed):
     return out
 
 
+VOC = ["alpha", "beta", "gamma", "delta", "epsilon", "zeta", "theta", "lambda", "sigma", "omega", "alphabet", "betamax",
+       "gammaray", "deltoid", "zebra", "thermal", "lambent", "signal", "omen", "al", "be", "ga"]
+
+
+def custom_index(rng, ndocs=6000, shards=4):
+    """documents with repeated words (long position lists -> overflow kernel), two text fields, multi-valued facets,
+    a float and an integer field, over four shards"""
+    docs = []
+    for i in range(ndocs):
+        n1 = rng.choice([1, 2, 3, 5, 8, 20, 45]) if rng.random() < 0.15 else rng.randrange(1, 7)
+        t1 = " ".join(rng.choice(VOC[:12] if rng.random() < 0.7 else VOC) for _ in range(n1))
+        t2 = " ".join(rng.choice(VOC) for _ in range(rng.randrange(0, 4)))
+        d = {"id": i, "title": t1, "body": t2, "price": round(rng.random() * 500, 2) if rng.random() < 0.9 else float(rng.randrange(100)),
+             "stock": rng.randrange(0, 50), "brand": rng.choice(["acme", "zenith", "orbit", "nadir", "apex"]),
+             "tags": [rng.choice(["t%02d" % k for k in range(30)]) for _ in range(rng.randrange(0, 4))], "instock": rng.random() < 0.6}
+        docs.append(d)
+    settings = {"indexedFields": ["title", "body", "price", "stock", "instock"], "facetFields": ["brand", "tags"], "hitsPerPage": 20}
+    return Index(settings, num_shards=shards).add_documents(docs)
+
+
+def custom_queries(rng, n):
+    rules = ["typos", "proximity", "position", "exact", "field"]
+    out = []
+    for _ in range(n):
+        q = {"q": " ".join(mutate(rng, rng.choice(VOC)) for _ in range(rng.randrange(0, 5)))}
+        if rng.random() < 0.3:
+            q["rankAlgorithm"] = rng.sample(rules, rng.randrange(1, 6))
+        if rng.random() < 0.15:
+            q["typos"] = False
+        if rng.random() < 0.3:
+            q["prefix"] = rng.choice(["last", "all", "none"])
+        r = rng.random()
+        if r < 0.35:
+            q["rankBy"] = {rng.choice(["price", "stock"]): rng.choice(["asc", "desc"])}
+        elif r < 0.5:
+            q["sortBy"] = {rng.choice(["price", "stock"]): rng.choice(["asc", "desc"])}
+        if rng.random() < 0.4:
+            f = rng.choice([{"brand": rng.choice(["acme", "orbit", "nope"])}, {"instock": True}, {"stock": {"$gte": rng.randrange(0, 50)}},
+                            {"price": {"$gt": rng.random() * 400, "$lte": 450.0}}, {"tags": {"$in": ["t01", "t17", "t29"]}},
+                            {"brand": {"$ne": "acme"}}, {"stock": rng.randrange(0, 50)}])
+            if rng.random() < 0.3:
+                f = {"$and": [f, {"$or": [{"instock": False}, {"tags": "t05"}]}]}
+            q["filter"] = f
+        if rng.random() < 0.3:
+            q["aggs"] = {"p": {rng.choice(["stats", "avg", "max", "min"]): {"field": "stock"}}}
+            if rng.random() < 0.5:
+                q["aggs"]["c"] = {"cardinality": {"field": rng.choice(["brand", "tags"])}}
+        q["hitsPerPage"] = rng.choice([0, 5, 20, 100, 500])
+        q["maxHits"] = max(q["hitsPerPage"], rng.choice([0, 100, 1000])) if q["hitsPerPage"] else 0
+        if q["hitsPerPage"] and rng.random() < 0.2:
+            q["page"] = rng.randrange(1, 3)
+        q["maxFacetResults"] = rng.choice([0, 2, 10, 40])
+        out.append(q)
+    return out
+
+
 def run(ix, eng, qs, tag):
     pqs, kept = [], []
     for q in qs:
         try:
             pqs.append(ix.query(dict(q, fullScan=True))); kept.append(q)
-        except QueryError:
+        except (QueryError, KeyError, ValueError):
             pass
     bad = 0
     for b in range(0, len(pqs), 16):
         got = eng.search(pqs[b:b + 16], capture=3)
         for pq, g, q in zip(pqs[b:b + 16], got, kept[b:b + 16]):
             o = orc_py.search(ix, pq, flags=3)
+            fields = RANK_FIELDS
+            if "rankAlgorithm" in q:       # only the named rules (and the rankBy / sortBy value) order the hits
+                fields = tuple(q["rankAlgorithm"]) + (("compare",) if ("rankBy" in q or "sortBy" in q) else ())
             try:
-                compare_results(g, o, ctx=q)
+                compare_results(g, o, ctx=q, key_fields=fields)
             except AssertionError as e:
                 bad += 1
                 print("MISMATCH", tag, q, str(e)[:200])
@@ -124,8 +183,12 @@ def main(rounds=200, seed=1):
     e2 = GpuEngine(ix2)
     n2, b2 = run(ix2, e2, zipf_queries(rng, lib, rounds, V, S), "zipf")
     e2.close(); ix2.close()
-    print("fuzz: %d + %d queries, %d + %d mismatches" % (n1, n2, b1, b2))
-    return b1 + b2
+    ix3 = custom_index(rng)
+    e3 = GpuEngine(ix3)
+    n3, b3 = run(ix3, e3, custom_queries(rng, rounds), "custom")
+    e3.close(); ix3.close()
+    print("fuzz: %d + %d + %d queries, %d + %d + %d mismatches" % (n1, n2, n3, b1, b2, b3))
+    return b1 + b2 + b3
 
 
 if __name__ == "__main__":
