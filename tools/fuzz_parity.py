@@ -178,7 +178,7 @@ def main(rounds=200, seed=1):
     n1, b1 = run(ix1, e1, datagen_queries(rng, rounds), "datagen")
     e1.close(); ix1.close()
     V, S = 2048, 5
-    shards = [lib.msynth_zipf(40_000, V, 20_000, S, s, 2) for s in range(2)]
+    shards = [lib.msynth_zipf(140_000, V, 20_000, S, s, 2) for s in range(2)]      # 70k docs per shard: three formula windows
     ix2 = Index.from_shards({}, shards, ["str"], ["num", "price"], ["flag"], ["cat", "hc"])
     e2 = GpuEngine(ix2)
     n2, b2 = run(ix2, e2, zipf_queries(rng, lib, rounds, V, S), "zipf")
