@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <memory>
 #include <vector>
 #include "mgpu_types.h"
 
@@ -507,7 +508,8 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
     const double t_begin = wall_ms();
 
     // ---------------- lower plans into host staging ----------------
-    std::vector<SqDev> sqd(n);
+    std::unique_ptr<SqDev[]> sqd_store(new SqDev[n]);     // not value-initialised: every element is memset below
+    SqDev *sqd = sqd_store.get();
     std::vector<SqHost> sqh(n);
     std::vector<uint32_t> blob;
     struct PendingScatter { int sq; int row; const uint32_t *src_dev; uint64_t n; };
@@ -532,6 +534,7 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
     struct SelOff { size_t cand0, cand1, hist, ctl, outidx, andor; uint32_t mcap; };
     std::vector<SelOff> seloff;
 
+    std::vector<uint32_t> sl, dl, fo, pl;       // per-squery scratch lists, reused (cleared, capacity kept)
     for (int i = 0; i < n; i++) {
         const mgpu_plan_t &p = plans[i];
         mgpu_shard *sh = shards[i];
@@ -564,7 +567,7 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
 
         // a term's sparse postings are not expanded into rows: k_formula ORs the part of each list that
         // falls into a workgroup's window straight into an LDS tile (list table below)
-        std::vector<uint32_t> sl;
+        sl.clear();
         auto use_term_posting = [&](uint32_t pid, int t, std::vector<uint32_t> *dense_list) -> int {
             if (pid >= sd.num_postings) return fail(MGPU_E_ARG, "posting id out of range");
             int32_t di = sh->post_dense[pid];
@@ -591,7 +594,7 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
         } else {
             q.num_terms = nt;
             for (int t = 0; t < nt; t++) {
-                std::vector<uint32_t> dl;
+                dl.clear();
                 const int row = -1;
                 uint64_t tc = 0;
                 q.term_sl[t] = (uint32_t)(sl.size() / 4);
@@ -635,7 +638,7 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
             int depth = 0;
             q.fops_off = (uint32_t)blob.size();
             q.num_fops = p.num_fops;
-            std::vector<uint32_t> fo;
+            fo.clear();
             for (int j = 0; j < p.num_fops; j++) {
                 const mgpu_fop_t &op = p.fops[j];
                 int a = 0;
@@ -672,7 +675,7 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
         }
         // flattened plan for k_formula (staged into LDS by every workgroup)
         {
-            std::vector<uint32_t> pl;
+            pl.clear();
             uint32_t at = 0;
             for (int t = 0; t <= q.num_terms; t++) {
                 pl.push_back(at);
@@ -973,7 +976,7 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
         }
     }
     // staging copy
-    memcpy(c->pin + up_sq, sqd.data(), sizeof(SqDev) * n);
+    memcpy(c->pin + up_sq, sqd, sizeof(SqDev) * n);
     if (!blob.empty()) memcpy(c->pin + up_blob, blob.data(), blob.size() * 4);
     if (!items.empty()) memcpy(c->pin + up_items, items.data(), items.size() * sizeof(ScatterItem));
     if (!seljobs.empty()) { memcpy(c->pin + up_sel, seljobs.data(), seljobs.size() * sizeof(SelJob));
