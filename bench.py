@@ -82,7 +82,7 @@ def main():
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="multi-rank rehearsal on ONE GPU: gloo collectives on host tensors, every rank on cuda:0")
     ap.add_argument("--no-latency", action="store_true", help="skip the 200 single-query latency probes (cleaner kernel profiles)")
-    ap.add_argument("--inflight", type=int, default=6, help="batches kept in flight per GPU (host threads x contexts)")
+    ap.add_argument("--inflight", type=int, default=7, help="batches kept in flight per GPU (host threads x contexts)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
