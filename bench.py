@@ -8,7 +8,7 @@ field, top-10, fullScan.  A "step" is one batch of queries taken through execute
 shard (plan lowering + GPU launches) and the form_result merge.
 
   N = 1 : all 8 shards on one GPU.
-  N > 1 : shards split over the ranks (8/N each, fixed corpus => strong scaling); every rank runs
+  N > 1 : shards split over the ranks (8/N each; the corpus is fixed but the queries per step grow with N, so a rank's work per step is constant => weak scaling); every rank runs
           the whole query batch on its shards, per-shard result slots are gathered to rank 0 with
           RCCL (torch.distributed all_gather over xGMI) and merged there.
 
@@ -123,7 +123,7 @@ def main():
     mirror_bytes = sum(lib.mgpu_shard_bytes(lib.mmirror_gpu(m)) for m in eng.mirrors)
 
     # queries per step grow with the number of GPUs so that a rank's batch (queries x its shards)
-    # keeps the same size: the corpus is fixed (strong scaling), the query stream is not
+    # keeps the same size: the corpus is fixed, the query stream is not: per-GPU work per step is constant (weak scaling)
     B = args.batch * world
     nq_pool = max(256, 2 * B)
     pool = [ix.query(j) for j in make_queries(lib, nq_pool)]
@@ -311,7 +311,7 @@ def main():
         line = {
             "metric": "queries/sec, 10M-doc index, 3-term typo+prefix query w/ facets",
             "value": round(qps, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "configs[2]: %d docs Zipf corpus, %d shards, 3-word typo+prefix query, 2 facet fields, "
                                    "rankBy num desc, top-10, fullScan" % (args.docs, TOTAL_SHARDS),
