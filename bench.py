@@ -9,8 +9,8 @@ shard (plan lowering + GPU launches) and the form_result merge.
 
   N = 1 : all 8 shards on one GPU.
   N > 1 : shards split over the ranks (8/N each; the corpus is fixed but the queries per step grow with N, so a rank's work per step is constant => weak scaling); every rank runs
-          the whole query batch on its shards, per-shard result slots are gathered to rank 0 with
-          RCCL (torch.distributed all_gather over xGMI) and merged there.
+          the whole query batch on its shards, per-shard result slots are exchanged with ONE RCCL
+          all_gather (torch.distributed over xGMI) and every rank merges its share of the queries.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant
 kernel stage (HIP-event timed on the launch stream) and `cpu_baseline` (the C oracle = port of the
