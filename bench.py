@@ -137,7 +137,7 @@ def main():
     if world > 1:
         from marlin_amd.dist import ShardGather
         gather = ShardGather(lib, dist, world, rank, B, local, K_TOP, NF, FMAX, NAGG,
-                             device=None if args.rehearse_gloo else "cuda:%d" % local_rank)
+                             device=None if args.rehearse_gloo else "cuda:%d" % local_rank, nslots=max(1, args.inflight))
 
     # Term lookup (the dtrie walk of lookup_terms) is outside the north-star path ("per-shard
     # query execution after term lookup"): resolve it once per distinct batch, before timing.
@@ -162,14 +162,16 @@ def main():
         if world == 1:
             hits = lib.m_form_result_batch(qarr, outs, B, local, None, 0)
         else:
+            gather.pack(outs, slot)
             with order:
                 while seq is not None and gather_turn[0] != seq:
                     if gather_turn[0] < 0:
                         raise RuntimeError("another host thread failed")
                     order.wait()
-                sq = gather.gather(outs, share=True)     # one RCCL all_gather of fixed-size result slots
+                gather.issue(slot)                       # one RCCL all_gather of fixed-size result slots, in step order
                 gather_turn[0] += 1
                 order.notify_all()
+            sq = gather.finish(slot, share=True)         # waits for this slot's copies only
             # every rank merges its own share of the batch's queries (the gather delivered all slots everywhere)
             mine = gather.my_queries()
             if mine:

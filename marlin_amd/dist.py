@@ -13,7 +13,9 @@ from . import ffi
 
 
 class ShardGather:
-    def __init__(self, lib, dist, world, rank, nq, local_shards, k_top, num_facets, fmax, num_aggs, device=None):
+    def __init__(self, lib, dist, world, rank, nq, local_shards, k_top, num_facets, fmax, num_aggs, device=None, nslots=1):
+        """nslots: buffer sets, one per batch in flight (a host thread packs and unpacks in its own set, so only
+        the enqueue of the collective itself has to happen in step order)"""
         import torch
         self.lib, self.dist, self.world, self.rank = lib, dist, world, rank
         self.nq, self.local = nq, local_shards
@@ -22,54 +24,66 @@ class ShardGather:
         n = nq * local_shards * self.slot_b
         self.on_gpu = device is not None and str(device).startswith("cuda")
         self.device = torch.device(device) if self.on_gpu else None
-        self.host_send = torch.empty(n, dtype=torch.uint8)
-        self.host_recv = torch.empty(world * n, dtype=torch.uint8)
-        if self.on_gpu:
-            self.host_send = self.host_send.pin_memory(); self.host_recv = self.host_recv.pin_memory()
-            self.send = torch.empty(n, dtype=torch.uint8, device=device)
-            self.recv = torch.empty(world * n, dtype=torch.uint8, device=device)
+        self.bufs = []
+        for _ in range(max(1, nslots)):
+            b = {"host_send": torch.empty(n, dtype=torch.uint8), "host_recv": torch.empty(world * n, dtype=torch.uint8), "event": None}
+            if self.on_gpu:
+                b["host_send"] = b["host_send"].pin_memory(); b["host_recv"] = b["host_recv"].pin_memory()
+                b["send"] = torch.empty(n, dtype=torch.uint8, device=device)
+                b["recv"] = torch.empty(world * n, dtype=torch.uint8, device=device)
+                b["event"] = torch.cuda.Event()
+            self.bufs.append(b)
         self.torch = torch
 
     def my_queries(self):
         """indices of the batch's queries this rank merges when every rank takes a share"""
         return list(range(self.rank, self.nq, self.world))
 
-    def gather(self, outs, share=False):
-        """outs: ctypes SqResult array [query][local shard] of this rank.
-        share=False: returns, on rank 0, a SqResult array [query][global shard] (None elsewhere).
-        share=True : every rank gets the [query][global shard] array of ITS share of the queries
-        (my_queries()): all_gather already delivers every slot everywhere, so the merge spreads over
-        the ranks with no further communication.  The caller frees the array with free()."""
-        lib = self.lib
+    # ---- the three steps of a gather; only issue() has to run in the same order on every rank
+    def pack(self, outs, slot=0):
+        """outs: ctypes SqResult array [query][local shard] of this rank -> the slot's send buffer.  The slot's
+        previous gather has been finished (finish() waits for its copies), so the buffer is free."""
+        self.lib.m_slot_pack_batch(outs, self.nq * self.local, *self.shape, self.bufs[slot]["host_send"].data_ptr())
+
+    def issue(self, slot=0):
+        """enqueue copy-in, all_gather and copy-out (RCCL over xGMI when the tensors live on the GPUs)"""
+        b = self.bufs[slot]
         if self.on_gpu:
             # torch's current device is per thread and the callers are worker threads: name the device
             self.torch.cuda.set_device(self.device)
-            stream = self.torch.cuda.current_stream(self.device)
-            # the previous call's async copy out of host_send must have run before it is overwritten;
-            # wait on torch's stream only (a device-wide sync would stall the other contexts' batches)
-            stream.synchronize()
-        lib.m_slot_pack_batch(outs, self.nq * self.local, *self.shape, self.host_send.data_ptr())
-        if self.on_gpu:
-            self.send.copy_(self.host_send, non_blocking=True)
-            self.dist.all_gather_into_tensor(self.recv, self.send)
-            if self.rank != 0 and not share:
-                return None
-            self.host_recv.copy_(self.recv, non_blocking=True)
-            stream.synchronize()
+            b["send"].copy_(b["host_send"], non_blocking=True)
+            self.dist.all_gather_into_tensor(b["recv"], b["send"])
+            b["host_recv"].copy_(b["recv"], non_blocking=True)
+            b["event"].record(self.torch.cuda.current_stream(self.device))
         else:
-            self.dist.all_gather_into_tensor(self.host_recv, self.host_send)
-            if self.rank != 0 and not share:
-                return None
+            self.dist.all_gather_into_tensor(b["host_recv"], b["host_send"])
+
+    def finish(self, slot=0, share=False):
+        """share=False: returns, on rank 0, a SqResult array [query][global shard] (None elsewhere).
+        share=True : every rank gets the [query][global shard] array of ITS share of the queries
+        (my_queries()): all_gather already delivers every slot everywhere, so the merge spreads over
+        the ranks with no further communication.  The caller frees the array with free()."""
+        lib, b = self.lib, self.bufs[slot]
+        if self.on_gpu:
+            b["event"].synchronize()
+        if self.rank != 0 and not share:
+            return None
         total = self.world * self.local
         if share:
             mine = len(self.my_queries())
             sq = (ffi.SqResult * max(1, mine * total))()
-            lib.m_slot_unpack_gathered_subset(self.host_recv.data_ptr(), self.world, self.nq, self.local, *self.shape,
+            lib.m_slot_unpack_gathered_subset(b["host_recv"].data_ptr(), self.world, self.nq, self.local, *self.shape,
                                               self.rank, self.world, sq)
             return sq
         sq = (ffi.SqResult * (self.nq * total))()
-        lib.m_slot_unpack_gathered(self.host_recv.data_ptr(), self.world, self.nq, self.local, *self.shape, sq)
+        lib.m_slot_unpack_gathered(b["host_recv"].data_ptr(), self.world, self.nq, self.local, *self.shape, sq)
         return sq
+
+    def gather(self, outs, share=False, slot=0):
+        """pack + issue + finish in one call"""
+        self.pack(outs, slot)
+        self.issue(slot)
+        return self.finish(slot, share)
 
     def free(self, sq):
         self.lib.m_sqresult_free_batch(sq, len(sq))

@@ -38,13 +38,15 @@ lib.m_form_result_batch(qarr, outs, nq, 2, res, 1)
 direct = [result_view(res[i], pqs[i]) for i in range(nq)]
 eng.free_raw(outs)
 # through the gather, twice in a row from two worker threads (slot reuse, per-thread device state)
-g = ShardGather(lib, dist, 1, 0, nq, 2, 100, len(ix.facets), 40, 4, device="cuda:0")
+g = ShardGather(lib, dist, 1, 0, nq, 2, 100, len(ix.facets), 40, 4, device="cuda:0", nslots=2)
 got = {}
 lock = threading.Lock()
 def work(t):
     o = eng.execute_prepared(prep, t)
+    g.pack(o, t)                    # own buffer set: packing and unpacking run outside the ordering lock
     with lock:
-        sq = g.gather(o, share=True)
+        g.issue(t)
+    sq = g.finish(t, share=True)
     r = (ffi.Result * nq)()
     lib.m_form_result_batch(qarr, sq, nq, 2, r, 1)
     got[t] = [result_view(r[i], pqs[i]) for i in range(nq)]
