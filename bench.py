@@ -150,16 +150,18 @@ def main():
     order = threading.Condition()
     gather_turn = [0]
 
+    qsub_cache = {}
+
     def run_step(step, slot=0, seq=None):
         """one batch: GPU execute_squery for every (query, shard) + the form_result merge.  With
         --gpus > 1 the cross-rank gather of step `seq` waits for its turn, so every rank issues its
         collectives in the same order whatever the host threads do."""
         prep = prepared[step % nbatches]
         pqs = prep[2]
-        qarr = (C.POINTER(ffi.Query) * B)(*[p.q for p in pqs])
         outs = eng.execute_prepared(prep, slot)
         hits = 0
         if world == 1:
+            qarr = (C.POINTER(ffi.Query) * B)(*[p.q for p in pqs])
             hits = lib.m_form_result_batch(qarr, outs, B, local, None, 0)
         else:
             gather.pack(outs, slot)
@@ -175,8 +177,10 @@ def main():
             # every rank merges its own share of the batch's queries (the gather delivered all slots everywhere)
             mine = gather.my_queries()
             if mine:
-                qsub = (C.POINTER(ffi.Query) * len(mine))(*[pqs[i].q for i in mine])
-                hits = lib.m_form_result_batch(qsub, sq, len(mine), TOTAL_SHARDS, None, 0)
+                key = step % nbatches                    # the pointer array of a prepared batch is built once
+                if key not in qsub_cache:
+                    qsub_cache[key] = (C.POINTER(ffi.Query) * len(mine))(*[pqs[i].q for i in mine])
+                hits = lib.m_form_result_batch(qsub_cache[key], sq, len(mine), TOTAL_SHARDS, None, 0)
             gather.free(sq)
         eng.free_raw(outs)
         return hits
