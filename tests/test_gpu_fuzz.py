@@ -3,7 +3,7 @@ pages, facets with small and large cut-offs, aggregations incl. cardinality, fac
 test corpus (multi-valued facets), on a two-shard Zipf corpus with a sparse 20000-value facet field and on a
 four-shard corpus with repeated words, floats and custom rank rule sets; the GPU
 path must equal the CPU oracle per shard (bitmap words, every rank record, top-2N, facets, aggs) and merged.
-tools/fuzz_parity.py runs the same generator for as long as one likes (20000 queries were clean)."""
+tools/fuzz_parity.py runs the same generator for as long as one likes (45000 queries were clean)."""
 import os
 import sys
 
