@@ -525,6 +525,7 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
     Bump cln;          // self-cleaned pool (its own allocation, see mgpu_ctx)
     std::vector<int> nrows(n, 0);
     uint32_t max_nblk = 1, max_N = 1, max_pblocks = 1, max_fk = 1, max_selm = 1, max_tab = 1, max_fac_k = 0, max_fac_nord = 0, max_lds_bins = 0;
+    bool sel_wide = false;            // some selection may need the wide (many-workgroup) passes or the stand-alone sorts
 
     struct Offs {      // arena offsets per squery (zero or nonzero region relative)
         size_t rows, hist[MGPU_MAX_FIELDS], touched[MGPU_MAX_FIELDS], ntouched[MGPU_MAX_FIELDS], facord[MGPU_MAX_FIELDS], andor, ovfcnt, docmap, blk, hits, khi, klo, ovfl, aggpart;
@@ -801,6 +802,7 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
             so.hist = cln.take(MG_SEL_BINS * 4); so.ctl = zer.take(SEL_WORDS * 4); so.outidx = nz.take((size_t)MG_SEL_FINAL * 4);
             seloff.push_back(so); jobfix.push_back({i, 0, 0});
             max_selm = std::max(max_selm, q.hit_cap);
+            if (q.hit_cap > MG_SEL_MID_KEYS || h.k > MG_SEL_SOLO_K) sel_wide = true;
         }
         for (int j = 0; j < h.nfac; j++) {
             int f = h.fac_field[j];
@@ -811,6 +813,8 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
             so.andor = zer.take(32, 8);
             seloff.push_back(so); jobfix.push_back({i, 1, j});
             max_selm = std::max(max_selm, so.mcap);
+            // (a field counted straight from the rank kernel is selected over one key per hit)
+            if (std::max(so.mcap, q.hit_cap) > MG_SEL_MID_KEYS || h.fac_k[j] > MG_SEL_SOLO_K) sel_wide = true;
         }
     }
     // batch-wide work list of hit tiles, filled by k_scan
@@ -1017,7 +1021,7 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
     mgk_card(st, UP + up_card, (uint32_t)cardjobs.size(), max_fk);
     mark();
     mgk_select(st, (const SelJob *)(UP + up_sel), UP + up_selout, (uint32_t)seljobs.size(), max_selm, MG_SEL_PASSES, 0,
-               NZ + off_items, sel_cap_items, (uint32_t *)(Z + off_todocnt), (uint32_t *)(NZ + off_todo));
+               NZ + off_items, sel_wide ? sel_cap_items : 0u, (uint32_t *)(Z + off_todocnt), (uint32_t *)(NZ + off_todo));
     mark();
     HIPCHK(hipMemcpyAsync(c->pin_out, R, res_bytes, hipMemcpyDeviceToHost, st));
     if (prof) { (void)hipEventRecord(c->ev[evi++], st); } else { (void)hipEventRecord(c->ev[1], st); }

@@ -1938,7 +1938,11 @@ void mgk_select(hipStream_t st, const SelJob *jobs, const void *outs, uint32_t n
         }
         // ... then the wide launches over exactly the workgroups the long lists asked for, and the
         // stand-alone sorts for the jobs on the final list
-        if (cap_items) {
+        // (cap_items == 0: the host knows that no job of the batch is longer than one mid workgroup's list or
+        // wants more than MG_SEL_SOLO_K keys, so nothing lands on the wide lists or the final list; should a
+        // job do so all the same, its out_n stays "not finished" and the host-driven rounds pick it up)
+        if (!cap_items) return;
+        {
             uint32_t g = cap_items < 2048 ? cap_items : 2048;
             for (int p = 0; p < SEL_WIDE_LAUNCHES; p++)
                 hipLaunchKernelGGL(k_select_items, dim3(g), dim3(MG_BLOCK), 0, st, jobs, so, L, p);
