@@ -77,7 +77,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=24)
     ap.add_argument("--docs", type=int, default=10_000_000)
     ap.add_argument("--batch", type=int, default=128, help="queries per step and GPU")
-    ap.add_argument("--cpu-queries", type=int, default=4)
+    ap.add_argument("--cpu-queries", type=int, default=256,
+                    help="bench queries the one-core CPU baseline runs (about 13 s of CPU work at the default)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="multi-rank rehearsal on ONE GPU: gloo collectives on host tensors, every rank on cuda:0")
@@ -297,7 +298,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu:
         from oracle import orc_py
         orc_py.load()
-        n = args.cpu_queries
+        n = max(1, min(args.cpu_queries, len(pool)))
         orc_py.lookup_time(True)
         t1 = time.perf_counter()
         chk = 0
