@@ -167,6 +167,12 @@ void mgpu_ctx_destroy(mgpu_ctx_t *c);
  * shards must live on the context's device.  outs[i] is filled (free with mgpu_sqout_free). */
 int  mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_plan_t *plans, int n,
                   mgpu_sqout_t *outs);
+/* The same in two halves, for callers that keep several batches in flight (the threadpool of query.c:435-452
+ * with a batch as the unit of work): begin lowers the plans and enqueues every copy and kernel on the context's
+ * stream, then returns; end waits and fills outs.  One batch per context at a time; shards and plans must stay
+ * valid until end.  mgpu_execute = begin + end. */
+int  mgpu_execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_plan_t *plans, int n);
+int  mgpu_execute_end(mgpu_ctx_t *c, mgpu_sqout_t *outs);
 /* sqresult_free (squery.c:336-356) */
 void mgpu_sqout_free(mgpu_sqout_t *o);
 
@@ -188,6 +194,7 @@ void mgpu_ctx_set_profiling(mgpu_ctx_t *c, int on);
  * 1 or, 2 andnot.  out_words may be NULL; returns the cardinality in *card. */
 int mgpu_posting_op(mgpu_ctx_t *c, mgpu_shard_t *s, int op, uint32_t pid_a, uint32_t pid_b,
                     uint64_t *out_words, uint32_t nwords, uint64_t *card);
+
 
 #ifdef __cplusplus
 }

@@ -34,7 +34,9 @@ void mgk_select(hipStream_t st, const SelJob *jobs, const void *outs, uint32_t n
                 void *items_mem, uint32_t cap_items, uint32_t *counters, uint32_t *fin_list);
 void mgk_row_op(hipStream_t st, const unsigned long long *a, const unsigned long long *b, unsigned long long *out,
                 uint32_t W, int op, unsigned long long *card);
+void mgk_fetch(hipStream_t st, void *dst, const void *src_pinned, size_t bytes);
 }
+
 
 struct FkJob { const uint32_t *hist; const uint32_t *ord2id; const uint32_t *touched; const uint32_t *ntouched;
                u64 *key_hi, *key_lo; u64 *andor; };
@@ -326,6 +328,7 @@ struct mgpu_ctx {
     // select passes); a batch that does not run to its end leaves `cln_dirty` set and the next one clears it.
     Arena cln; bool cln_dirty = true;
     uint32_t *pool_used = nullptr;
+    struct Pending *pend = nullptr;                    // the batch in flight (execute_begin .. execute_end)
     hipEvent_t ev[MGPU_NUM_STAGES + 1];
     int profiling;
     float stage_ms[MGPU_NUM_STAGES];
@@ -350,10 +353,12 @@ extern "C" int mgpu_ctx_create(int device, uint64_t scratch_bytes, mgpu_ctx_t **
     return MGPU_OK;
 }
 
+static void pending_free(struct Pending *p);
 extern "C" void mgpu_ctx_destroy(mgpu_ctx_t *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    pending_free(c->pend);
     if (c->arena.dev) (void)hipFree(c->arena.dev);
     if (c->cln.dev) (void)hipFree(c->cln.dev);
     if (c->pin) (void)hipHostFree(c->pin);
@@ -437,6 +442,40 @@ struct SqHost {                          // host bookkeeping for one squery of t
     uint64_t sparse_docs;                // sparse posting entries of the terms (read once per squery by k_formula)
 };
 
+// ---- state of one batch between its launch (execute_begin) and its decode (execute_end); kept in the context
+// and reused from batch to batch, so that the vectors keep their capacity
+struct PendingScatter { int sq; int row; const uint32_t *src_dev; uint64_t n; };
+struct JobFix { int sq; int kind; int field; };       // kind 0 rank, 1 facet
+struct Offs {      // arena offsets per squery (zero or nonzero region relative)
+    size_t rows, hist[MGPU_MAX_FIELDS], touched[MGPU_MAX_FIELDS], ntouched[MGPU_MAX_FIELDS], facord[MGPU_MAX_FIELDS], andor, ovfcnt, docmap, blk, hits, khi, klo, ovfl, aggpart;
+    size_t fkhi[MGPU_MAX_FIELDS], fklo[MGPU_MAX_FIELDS];
+};
+struct SelOff { size_t cand0, cand1, hist, ctl, outidx, andor; uint32_t mcap; };
+struct Pending {
+    bool active = false;
+    int n = 0;
+    mgpu_shard_t *const *shards = nullptr; const mgpu_plan_t *plans = nullptr;
+    std::vector<SqDev> sqd;
+    std::vector<SqHost> sqh;
+    std::vector<uint32_t> blob;
+    std::vector<PendingScatter> pscat;
+    std::vector<SelJob> seljobs; std::vector<SelOut> selouts;
+    std::vector<FkJob> fkjobs; std::vector<CardJob> cardjobs;
+    std::vector<JobFix> jobfix;
+    std::vector<int> nrows;
+    std::vector<Offs> offs;
+    std::vector<SelOff> seloff;
+    std::vector<uint32_t> sl, dl, fo, pl;       // per-squery scratch lists
+    std::vector<ScatterItem> items;
+    // what the decode needs from the launch
+    size_t res_bytes = 0, nz_base = 0, up_bytes = 0, up_base = 0, up_sel = 0, up_selout = 0;
+    uint32_t max_selm = 0;
+    bool fuse_fk = false, prof = false;
+    int nev = 0;                                 // events recorded (profiling)
+    double t_begin = 0, t_lowered = 0;
+};
+
+
 static int build_key_layout(const mgpu_plan_t &p, KeyField *kf, int *nkf) {
     int n = 0, acc = 0;
     bool seen[8] = {false, false, false, false, false, false, false, false};
@@ -499,43 +538,73 @@ extern "C" void mgpu_sqout_free(mgpu_sqout_t *o) {
     memset(o, 0, sizeof(*o));
 }
 
+static void pending_free(Pending *p) { delete p; }
+static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_plan_t *plans, int n);
+static int execute_end(mgpu_ctx_t *c, mgpu_sqout_t *outs, bool *completed);
+
+// Launch half of mgpu_execute: lowers the plans, lays out the arena, enqueues every copy and kernel of the batch on
+// the context's stream and returns without waiting.  `shards` and `plans` must stay valid until mgpu_execute_end.
+extern "C" int mgpu_execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_plan_t *plans, int n) {
+    if (!c || !shards || !plans || n <= 0) return fail(MGPU_E_ARG, "bad argument");
+    if (c->pend && c->pend->active) return fail(MGPU_E_ARG, "a batch is already in flight on this context");
+    if (!c->pend) c->pend = new Pending();
+    const int rc = execute_begin(c, shards, plans, n);
+    c->pend->active = rc == MGPU_OK;
+    return rc;
+}
+// Wait + decode half: outs[i] is filled as by mgpu_execute.
+extern "C" int mgpu_execute_end(mgpu_ctx_t *c, mgpu_sqout_t *outs) {
+    if (!c || !outs) return fail(MGPU_E_ARG, "bad argument");
+    if (!c->pend || !c->pend->active) return fail(MGPU_E_ARG, "no batch in flight on this context");
+    const int n = c->pend->n;
+    for (int i = 0; i < n; i++) memset(&outs[i], 0, sizeof(outs[i]));
+    bool completed = false;
+    const int rc = execute_end(c, outs, &completed);
+    c->pend->active = false;
+    // an early return (HIP failure) hands nothing back: whatever the decode had already allocated is released
+    // here, so that the caller owns arrays only when the batch ran to its end
+    if (!completed) for (int i = 0; i < n; i++) mgpu_sqout_free(&outs[i]);
+    return rc;
+}
+
 extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_plan_t *plans, int n,
                             mgpu_sqout_t *outs) {
-    if (!c || !shards || !plans || !outs || n <= 0) return fail(MGPU_E_ARG, "bad argument");
+    if (!outs) return fail(MGPU_E_ARG, "bad argument");
+    for (int i = 0; i < n; i++) memset(&outs[i], 0, sizeof(outs[i]));
+    const int rc = mgpu_execute_begin(c, shards, plans, n);
+    if (rc) return rc;
+    return mgpu_execute_end(c, outs);
+}
+
+static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_plan_t *plans, int n) {
     if (n > 65535) return fail(MGPU_E_LIMIT, "batch larger than 65535");
     HIPCHK(hipSetDevice(c->device));
-    for (int i = 0; i < n; i++) memset(&outs[i], 0, sizeof(outs[i]));
     const double t_begin = wall_ms();
+    Pending &P = *c->pend;
+    P.n = n; P.shards = shards; P.plans = plans;
 
     // ---------------- lower plans into host staging ----------------
-    std::unique_ptr<SqDev[]> sqd_store(new SqDev[n]);     // not value-initialised: every element is memset below
-    SqDev *sqd = sqd_store.get();
-    std::vector<SqHost> sqh(n);
-    std::vector<uint32_t> blob;
-    struct PendingScatter { int sq; int row; const uint32_t *src_dev; uint64_t n; };
-    std::vector<PendingScatter> pscat;
-    std::vector<SelJob> seljobs; std::vector<SelOut> selouts;
-    std::vector<FkJob> fkjobs; std::vector<CardJob> cardjobs;
-    struct JobFix { int sq; int kind; int field; };       // kind 0 rank, 1 facet
-    std::vector<JobFix> jobfix;
+    P.sqd.resize(n);                                       // every element is memset below
+    SqDev *sqd = P.sqd.data();
+    std::vector<SqHost> &sqh = P.sqh; sqh.resize(n);
+    std::vector<uint32_t> &blob = P.blob; blob.clear();
+    std::vector<PendingScatter> &pscat = P.pscat; pscat.clear();
+    std::vector<SelJob> &seljobs = P.seljobs; std::vector<SelOut> &selouts = P.selouts;
+    std::vector<FkJob> &fkjobs = P.fkjobs; fkjobs.clear();
+    std::vector<CardJob> &cardjobs = P.cardjobs; cardjobs.clear();
+    std::vector<JobFix> &jobfix = P.jobfix; jobfix.clear();
 
     Bump res;          // results region (inside the zero region, first)
     Bump zer;          // rest of the zero region
     Bump nz;           // non-zero region
     Bump cln;          // self-cleaned pool (its own allocation, see mgpu_ctx)
-    std::vector<int> nrows(n, 0);
+    std::vector<int> &nrows = P.nrows; nrows.assign(n, 0);
     uint32_t max_nblk = 1, max_N = 1, max_pblocks = 1, max_fk = 1, max_selm = 1, max_tab = 1, max_fac_k = 0, max_fac_nord = 0, max_lds_bins = 0;
     bool sel_wide = false;            // some selection may need the wide (many-workgroup) passes or the stand-alone sorts
 
-    struct Offs {      // arena offsets per squery (zero or nonzero region relative)
-        size_t rows, hist[MGPU_MAX_FIELDS], touched[MGPU_MAX_FIELDS], ntouched[MGPU_MAX_FIELDS], facord[MGPU_MAX_FIELDS], andor, ovfcnt, docmap, blk, hits, khi, klo, ovfl, aggpart;
-        size_t fkhi[MGPU_MAX_FIELDS], fklo[MGPU_MAX_FIELDS];
-    };
-    std::vector<Offs> offs(n);
-    struct SelOff { size_t cand0, cand1, hist, ctl, outidx, andor; uint32_t mcap; };
-    std::vector<SelOff> seloff;
-
-    std::vector<uint32_t> sl, dl, fo, pl;       // per-squery scratch lists, reused (cleared, capacity kept)
+    std::vector<Offs> &offs = P.offs; offs.resize(n);
+    std::vector<SelOff> &seloff = P.seloff; seloff.clear();
+    std::vector<uint32_t> &sl = P.sl, &dl = P.dl, &fo = P.fo, &pl = P.pl;
     for (int i = 0; i < n; i++) {
         const mgpu_plan_t &p = plans[i];
         mgpu_shard *sh = shards[i];
@@ -834,7 +903,7 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
     for (int i = 0; i < n; i++) offs[i].rows = zer.take((size_t)nrows[i] * sqd[i].sh.Wp * 8);      // filter operands only
 
     // scatter work items
-    std::vector<ScatterItem> items;
+    std::vector<ScatterItem> &items = P.items; items.clear();
     // region bases
     const size_t res_bytes = (res.off + 255) / 256 * 256;
     const size_t zero_bytes = res_bytes + ((zer.off + 255) / 256 * 256);
@@ -1001,30 +1070,76 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
     const bool prof = c->profiling != 0;
     int evi = 0;
     auto mark = [&]() { if (prof) (void)hipEventRecord(c->ev[evi++], st); };
+    // MGPU_TRACE_SUBMIT=1: wall clock after every enqueue step, printed when the launch half took more than 2 ms
+    static const bool trace_submit = getenv("MGPU_TRACE_SUBMIT") != nullptr;
+    double tt[12]; int ntt = 0;
+    auto tick = [&]() { if (trace_submit && ntt < 12) tt[ntt++] = wall_ms(); };
+    tick();
+    // Copies.  On this runtime a hipMemcpyAsync enqueued behind kernels of its own stream holds the calling host
+    // thread until those kernels have run (measured: 4-11 ms with eight batches in flight, profiles/README.md), a
+    // kernel launch returns at once.  So the upload goes FIRST, while the stream is still idle (the previous batch
+    // of this context was waited for), and the results are written to pinned host memory by a kernel (mgk_fetch).
+    // MGPU_COPY_MODE: 0 = both by hipMemcpyAsync (round 1), 1 = upload by hipMemcpyAsync first, results by kernel
+    // (default), 2 = both by kernel.
+    static const int copy_mode = getenv("MGPU_COPY_MODE") ? atoi(getenv("MGPU_COPY_MODE")) : 1;
     (void)hipEventRecord(c->ev[0], st); evi = 1;
+    if (copy_mode == 1) HIPCHK(hipMemcpyAsync(UP, c->pin, up_bytes, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(A, 0, zero_bytes, st));
     if (c->cln_dirty && c->cln.cap) HIPCHK(hipMemsetAsync(CL, 0, c->cln.cap, st));
     c->cln_dirty = true;                  // until this batch has run to its end
     HIPCHK(hipMemsetAsync(c->pool_used, 0, 4, st));
-    HIPCHK(hipMemcpyAsync(UP, c->pin, up_bytes, hipMemcpyHostToDevice, st));
+    tick();
+    if (copy_mode == 0) HIPCHK(hipMemcpyAsync(UP, c->pin, up_bytes, hipMemcpyHostToDevice, st));
+    else if (copy_mode == 2) mgk_fetch(st, UP, c->pin, up_bytes);             // up_bytes is a multiple of 256, both buffers 256-byte aligned
     mark();
+    tick();
     mgk_scatter(st, (const ScatterItem *)(UP + up_items), (uint32_t)items.size());
     mark();
     uint2 *d_tiles = (uint2 *)(NZ + off_tiles); uint32_t *d_tilecnt = (uint32_t *)(Z + off_tilecnt);
     mgk_formula(st, d_sq, d_blob, max_nblk, (uint32_t)n, d_tiles, d_tilecnt);
     mark();
+    tick();
     mgk_rank(st, d_sq, d_blob, max_N, (uint32_t)n, max_tab, d_tiles, d_tilecnt, (uint32_t)tile_cap, c->pool, c->pool_used, c->pool_cap);
     mark();
     mgk_docproc(st, d_sq, (uint32_t)n, d_tiles, d_tilecnt, (uint32_t)tile_cap, max_lds_bins);
     mark();
+    tick();
     mgk_fkeys(st, UP + up_fk, (uint32_t)fkjobs.size(), max_fk);
     mgk_card(st, UP + up_card, (uint32_t)cardjobs.size(), max_fk);
     mark();
     mgk_select(st, (const SelJob *)(UP + up_sel), UP + up_selout, (uint32_t)seljobs.size(), max_selm, MG_SEL_PASSES, 0,
                NZ + off_items, sel_wide ? sel_cap_items : 0u, (uint32_t *)(Z + off_todocnt), (uint32_t *)(NZ + off_todo));
     mark();
-    HIPCHK(hipMemcpyAsync(c->pin_out, R, res_bytes, hipMemcpyDeviceToHost, st));
+    tick();
+    if (copy_mode == 0) HIPCHK(hipMemcpyAsync(c->pin_out, R, res_bytes, hipMemcpyDeviceToHost, st));
+    else mgk_fetch(st, c->pin_out, R, res_bytes);          // results written to pinned host memory by the GPU
     if (prof) { (void)hipEventRecord(c->ev[evi++], st); } else { (void)hipEventRecord(c->ev[1], st); }
+    tick();
+    HIPCHK(hipGetLastError());
+    if (trace_submit && ntt >= 7 && tt[6] - t_begin > 2.0)
+        fprintf(stderr, "[submit] lower %.3f | memsets %.3f h2d %.3f scatter+formula %.3f rank+docproc %.3f fkeys+select %.3f d2h %.3f ms\n",
+                tt[0] - t_begin, tt[1] - tt[0], tt[2] - tt[1], tt[3] - tt[2], tt[4] - tt[3], tt[5] - tt[4], tt[6] - tt[5]);
+    P.res_bytes = res_bytes; P.nz_base = nz_base; P.up_bytes = up_bytes; P.up_base = up_base; P.up_sel = up_sel; P.up_selout = up_selout;
+    P.max_selm = max_selm; P.fuse_fk = fuse_fk; P.prof = prof; P.nev = evi;
+    P.t_begin = t_begin; P.t_lowered = t_lowered;
+    c->host_ms[0] = (float)(t_lowered - t_begin);
+    return MGPU_OK;
+}
+
+static int execute_end(mgpu_ctx_t *c, mgpu_sqout_t *outs, bool *completed) {
+    Pending &P = *c->pend;
+    const int n = P.n;
+    mgpu_shard_t *const *shards = P.shards; const mgpu_plan_t *plans = P.plans;
+    SqDev *sqd = P.sqd.data();
+    std::vector<SqHost> &sqh = P.sqh;
+    std::vector<SelOff> &seloff = P.seloff; std::vector<JobFix> &jobfix = P.jobfix; std::vector<SelJob> &seljobs = P.seljobs;
+    const size_t res_bytes = P.res_bytes, nz_base = P.nz_base, up_bytes = P.up_bytes, up_sel = P.up_sel, up_selout = P.up_selout;
+    const uint32_t max_selm = P.max_selm;
+    const bool fuse_fk = P.fuse_fk, prof = P.prof;
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    char *A = c->arena.dev, *R = A, *UP = A + P.up_base, *CL = c->cln.dev;
+    const double t_wait0 = wall_ms();
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
 
@@ -1139,14 +1254,15 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
             // touched bins (at most one per facet value of a hit): bin index + count + id in, 16-byte key out
             const int f = h.fac_field[j];
             const double touched = std::min<double>((double)q.sh.fa_nord[f], (double)M * sh->avg_fv[f]);
-            c->stage_bytes[5] += (uint64_t)(touched * 28.0);
+            c->stage_bytes[fuse_fk ? 6 : 5] += (uint64_t)(touched * 28.0);   // the select kernels derive the keys when fuse_fk
         }
         if (h.k) c->stage_bytes[6] += 16 * M * (M > MG_SEL_SMALL ? 2 : 1);
     }
     c->stage_bytes[0] = up_bytes; c->stage_bytes[7] = res_bytes;
-    // the batch ran to its end: the self-cleaned pool is zero again (MGPU_CHECK_CLEAN makes sure of it)
-    c->cln_dirty = false;
-    if (getenv("MGPU_CHECK_CLEAN") && c->cln.cap) {
+    // the batch ran to its end: the self-cleaned pool is zero again (MGPU_CHECK_CLEAN makes sure of it) -- unless a
+    // job gave up (error word, selection that did not converge): its bins were never exchanged back to zero
+    c->cln_dirty = worst != MGPU_OK;
+    if (getenv("MGPU_CHECK_CLEAN") && c->cln.cap && worst == MGPU_OK) {
         uint32_t *flag = (uint32_t *)A;              // the arena is free again
         HIPCHK(hipMemsetAsync(flag, 0, 4, st));
         mgk_check_zero(st, CL, c->cln.cap, flag);
@@ -1155,8 +1271,9 @@ extern "C" int mgpu_execute(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mg
         HIPCHK(hipStreamSynchronize(st));
         if (hflag) { c->cln_dirty = true; return fail(MGPU_E_HIP, "self-cleaned pool was left dirty by this batch"); }
     }
-    c->host_ms[0] = (float)(t_lowered - t_begin); c->host_ms[1] = (float)(t_waited - t_lowered);
+    c->host_ms[1] = (float)(t_waited - t_wait0);         // time spent waiting in execute_end (the launch half returned earlier)
     c->host_ms[2] = (float)(wall_ms() - t_waited);
+    *completed = true;
     return worst;
 }
 

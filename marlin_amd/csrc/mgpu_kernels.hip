@@ -64,30 +64,32 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *total,
 // oper_or's array half (cont.c:431-435 array_cont_inplace_union) and num_*_filter's bmap_add
 // loop (filter_apply.c:44-54,159-166,182-191): sorted docid lists OR-ed into a zeroed dense row.
 // Lanes that hit the same u64 word are merged in-wave first, so one atomic goes out per word.
+__device__ __forceinline__ void scatter_chunk(const uint32_t *src, uint32_t n, u64 *dst) {
+    for (uint32_t base = 0; base < n; base += MG_BLOCK) {
+        uint32_t i = base + threadIdx.x;
+        bool valid = i < n;
+        uint32_t d = valid ? src[i] : 0xFFFFFFFFu;
+        uint32_t w = d >> 6;
+        u64 bit = valid ? (1ull << (d & 63)) : 0ull;
+        // sorted input: equal words are adjacent lanes; segmented OR by doubling
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t ow = __shfl_down(w, o, 64);
+            u64 ob = __shfl_down(bit, o, 64);
+            if (lane + o < 64 && ow == w) bit |= ob;
+        }
+        uint32_t pw = __shfl_up(w, 1, 64);
+        bool head = (lane == 0) || (pw != w);
+        if (valid && head) atomicOr(&dst[w], bit);
+    }
+}
 __global__ __launch_bounds__(MG_BLOCK) void k_scatter(const ScatterItem *items, uint32_t nitems) {
     for (uint32_t it = blockIdx.x; it < nitems; it += gridDim.x) {
         const ScatterItem s = items[it];
-        for (uint32_t base = 0; base < s.n; base += MG_BLOCK) {
-            uint32_t i = base + threadIdx.x;
-            bool valid = i < s.n;
-            uint32_t d = valid ? s.src[i] : 0xFFFFFFFFu;
-            uint32_t w = d >> 6;
-            u64 bit = valid ? (1ull << (d & 63)) : 0ull;
-            // sorted input: equal words are adjacent lanes; segmented OR by doubling
-            const int lane = threadIdx.x & 63;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                uint32_t ow = __shfl_down(w, o, 64);
-                u64 ob = __shfl_down(bit, o, 64);
-                if (lane + o < 64 && ow == w) bit |= ob;
-            }
-            uint32_t pw = __shfl_up(w, 1, 64);
-            bool head = (lane == 0) || (pw != w);
-            if (valid && head) atomicOr((u64 *)&s.dst[w], bit);
-        }
+        scatter_chunk(s.src, s.n, (u64 *)s.dst);
     }
 }
-
 // ------------------------------------------------------------------ formula + filter + popcount
 // get_matching_docids (squery.c:212-277) fused with squery_apply_filters (squery.c:377-395,
 // filter_apply.c:207-227) and bmap_cardinality (bmap.c:362-368).
@@ -1870,6 +1872,18 @@ void mgk_scatter(hipStream_t st, const ScatterItem *items, uint32_t nitems) {
     if (!nitems) return;
     uint32_t grid = nitems < 8192 ? nitems : 8192;
     hipLaunchKernelGGL(k_scatter, dim3(grid), dim3(MG_BLOCK), 0, st, items, nitems);
+}
+// The batch's lowered plans, fetched from pinned host memory by the GPU itself (16 bytes per lane over PCIe) instead
+// of a hipMemcpyAsync: on this runtime an H2D copy enqueued behind kernels of other streams was seen to hold the calling
+// host thread for milliseconds (profiles/README.md, round 2), a kernel launch returns at once.
+__global__ __launch_bounds__(MG_BLOCK) void k_fetch(uint4 *dst, const uint4 *src, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * MG_BLOCK + threadIdx.x; i < n16; i += (size_t)gridDim.x * MG_BLOCK) dst[i] = src[i];
+}
+void mgk_fetch(hipStream_t st, void *dst, const void *src_pinned, size_t bytes) {
+    const size_t n16 = (bytes + 15) / 16;
+    if (!n16) return;
+    size_t g = (n16 + MG_BLOCK - 1) / MG_BLOCK; if (g > 128) g = 128;
+    hipLaunchKernelGGL(k_fetch, dim3((uint32_t)g), dim3(MG_BLOCK), 0, st, (uint4 *)dst, (const uint4 *)src_pinned, n16);
 }
 // number of workgroups of the persistent kernels that stride over the tile work list
 static uint32_t worklist_grid(uint32_t tile_cap) {

@@ -116,8 +116,13 @@ class GpuEngine:
                 raise GpuError("mmirror_create: %d %s" % (rc, lib.mgpu_last_error().decode()))
             self.mirrors.append(m)
         self._marr = (C.c_void_p * len(self.mirrors))(*[m.value for m in self.mirrors])
+        self._pipe = None
+        self._pipe_n = 0
 
     def close(self):
+        if self._pipe is not None:
+            self.lib.msq_pipeline_destroy(self._pipe)
+            self._pipe = None
         for m in self.mirrors:
             self.lib.mmirror_destroy(m)
         self.mirrors = []
@@ -163,19 +168,42 @@ class GpuEngine:
             raise GpuError("msq_execute_prepared: %d %s" % (rc, self.lib.mgpu_last_error().decode()))
         return outs
 
-    def run_pipeline(self, preps, first, count, nthreads=None):
-        """`count` steps of the native serving loop (mplan.c:msq_run_pipeline): nthreads host threads, one
-        context each, step i = execute_prepared + form_result of preps[(first + i) % len(preps)];
-        returns the summed totalHits"""
+    def _pipeline(self, nthreads):
+        """the native serving loop's thread pool (mplan.c:msq_pipeline_*), created on first use and kept"""
         nthreads = len(self.ctxs) if nthreads is None else nthreads
         if nthreads > len(self.ctxs):
             raise ValueError("more pipeline threads than contexts")
-        carr = (C.c_void_p * nthreads)(*self.ctxs[:nthreads])
+        if self._pipe is not None and self._pipe_n != nthreads:
+            self.lib.msq_pipeline_destroy(self._pipe)
+            self._pipe = None
+        if self._pipe is None:
+            carr = (C.c_void_p * nthreads)(*self.ctxs[:nthreads])
+            h = C.c_void_p()
+            rc = self.lib.msq_pipeline_create(carr, nthreads, C.byref(h))
+            if rc:
+                raise GpuError("msq_pipeline_create: %d" % rc)
+            self._pipe, self._pipe_n = h, nthreads
+        return self._pipe
+
+    def warm_pipeline(self, preps, nthreads=None):
+        """every prepared batch once through every context of the pipeline: arenas, pinned buffers and the
+        histogram pools get their final size (set-up, like the mirror upload; not a measured step)"""
+        pipe = self._pipeline(nthreads)
+        parr = (C.c_void_p * len(preps))(*[p[0] for p in preps])
+        rc = self.lib.msq_pipeline_warm(pipe, parr, len(preps))
+        if rc:
+            raise GpuError("msq_pipeline_warm: %d %s" % (rc, self.lib.msq_pipeline_error(pipe).decode()))
+
+    def run_pipeline(self, preps, first, count, nthreads=None):
+        """`count` steps of the native serving loop (mplan.c:msq_pipeline_run): nthreads host threads, one
+        context each, step i = execute_prepared + form_result of preps[(first + i) % len(preps)];
+        returns the summed totalHits"""
+        pipe = self._pipeline(nthreads)
         parr = (C.c_void_p * len(preps))(*[p[0] for p in preps])
         hits = C.c_long(0)
-        rc = self.lib.msq_run_pipeline(carr, nthreads, parr, len(preps), first, count, C.byref(hits))
+        rc = self.lib.msq_pipeline_run(pipe, parr, len(preps), first, count, C.byref(hits))
         if rc:
-            raise GpuError("msq_run_pipeline: %d %s" % (rc, self.lib.mgpu_last_error().decode()))
+            raise GpuError("msq_pipeline_run: %d %s" % (rc, self.lib.msq_pipeline_error(pipe).decode()))
         return hits.value
 
     def free_prepared(self, prep):

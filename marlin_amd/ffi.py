@@ -168,6 +168,11 @@ def load():
         "msq_execute_prepared": (ci, [vp, vp, C.POINTER(SqResult)]),
         "msq_prepared_free": (None, [vp]),
         "msq_run_pipeline": (ci, [C.POINTER(vp), ci, C.POINTER(vp), ci, ci, ci, C.POINTER(C.c_long)]),
+        "msq_pipeline_create": (ci, [C.POINTER(vp), ci, C.POINTER(vp)]),
+        "msq_pipeline_warm": (ci, [vp, C.POINTER(vp), ci]),
+        "msq_pipeline_run": (ci, [vp, C.POINTER(vp), ci, ci, ci, C.POINTER(C.c_long)]),
+        "msq_pipeline_error": (C.c_char_p, [vp]),
+        "msq_pipeline_destroy": (None, [vp]),
         # GPU C ABI (include/marlin_gpu.h), reached through the same process image
         "mgpu_last_error": (C.c_char_p, []),
         "mgpu_device_count": (ci, []),

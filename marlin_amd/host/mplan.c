@@ -5,6 +5,7 @@
 #include <float.h>
 #include <stdio.h>
 #include <pthread.h>
+#include <time.h>
 
 /* ------------------------------------------------------------------ mirror export */
 int mmirror_create(const mshard_t *s, int device, mmirror_t **out) {
@@ -381,15 +382,18 @@ int msq_execute_batch(mgpu_ctx_t *ctx, mmirror_t *const *mirrors, int num_shards
 }
 
 /* the part of execute_squery after lookup_terms: bitmap formula, filter, ranking, facets, aggs,
- * top-2N (squery.c:480-536) as one GPU batch */
-int msq_execute_prepared(mgpu_ctx_t *ctx, const msq_prepared_t *pp, m_sqresult_t *outs) {
+ * top-2N (squery.c:480-536) as one GPU batch -- in two halves: submit enqueues the batch on the context's
+ * stream and returns, collect waits for it and fills outs.  One batch in flight per context. */
+int msq_submit_prepared(mgpu_ctx_t *ctx, const msq_prepared_t *pp) {
+    return mgpu_execute_begin(ctx, pp->gs, pp->gp, pp->n);
+}
+
+int msq_collect_prepared(mgpu_ctx_t *ctx, const msq_prepared_t *pp, m_sqresult_t *outs) {
     int n = pp->n, num_shards = pp->num_shards;
     mmirror_t *const *mirrors = pp->mirrors;
     const m_query_t *const *queries = (const m_query_t *const *)pp->queries;
-    mgpu_plan_t *gp = pp->gp; mgpu_shard_t **gs = pp->gs;
     mgpu_sqout_t *go = calloc((size_t)(n ? n : 1), sizeof(mgpu_sqout_t));
-    int rc = 0;
-    if (!rc) rc = mgpu_execute(ctx, gs, gp, n, go);
+    int rc = mgpu_execute_end(ctx, go);
     for (int i = 0; i < n; i++) {
         const m_query_t *q = queries[i / num_shards];
         int sidx = i % num_shards;
@@ -442,48 +446,205 @@ int msq_execute_prepared(mgpu_ctx_t *ctx, const msq_prepared_t *pp, m_sqresult_t
     return rc;
 }
 
-/* ------------------------------------------------------------------ pipelined serving loop
- * The shape query.c:319-383 has in the reference (a threadpool of workers, each running
- * execute_squery jobs and handing them to form_result), with a batch as the unit of work:
- * nthreads host threads, one GPU context each; thread t runs steps t, t + nthreads, ... and for each
- * step executes prepared batch (first + step) % nprep and merges every query of it (form_result).
- * Returns the first error code met (0 = none); *hits_out = sum of totalHits over all merged queries. */
-typedef struct {
-    mgpu_ctx_t *ctx; const msq_prepared_t *const *preps; int nprep, first, count, t, nthreads;
-    long hits; int rc;
-} pipe_job_t;
-
-static void *pipe_worker(void *arg) {
-    pipe_job_t *j = arg;
-    for (int i = j->t; i < j->count; i += j->nthreads) {
-        const msq_prepared_t *pp = j->preps[(j->first + i) % j->nprep];
-        m_sqresult_t *outs = calloc((size_t)(pp->n ? pp->n : 1), sizeof(m_sqresult_t));
-        if (!outs) { j->rc = -1; return NULL; }
-        int rc = msq_execute_prepared(j->ctx, pp, outs);
-        if (!rc) j->hits += m_form_result_batch((const m_query_t *const *)pp->queries, outs, pp->nq, pp->num_shards, NULL, 0);
-        m_sqresult_free_batch(outs, pp->n);
-        free(outs);
-        if (rc) { j->rc = rc; return NULL; }
-    }
-    return NULL;
+int msq_execute_prepared(mgpu_ctx_t *ctx, const msq_prepared_t *pp, m_sqresult_t *outs) {
+    int rc = msq_submit_prepared(ctx, pp);
+    if (rc) { memset(outs, 0, sizeof(*outs) * (size_t)pp->n); return rc; }
+    return msq_collect_prepared(ctx, pp, outs);
 }
 
-int msq_run_pipeline(mgpu_ctx_t *const *ctxs, int nthreads, const msq_prepared_t *const *preps, int nprep,
-                     int first, int count, long *hits_out) {
-    if (nthreads < 1 || nthreads > 64 || nprep < 1 || count < 0) return -1;
-    pipe_job_t jobs[64];
+/* ------------------------------------------------------------------ pipelined serving loop
+ * The shape query.c:426-484 has in the reference (a threadpool of workers, each running
+ * execute_squery jobs and handing them to form_result), with a batch as the unit of work:
+ * nthreads host threads, one GPU context each, started ONCE (msq_pipeline_create) and parked on a
+ * condition variable between runs; in a run thread t takes steps t, t + nthreads, ... and for each
+ * step executes prepared batch (first + step) % nprep and merges every query of it (form_result).
+ * msq_pipeline_warm takes every batch through every context once, so that each context's arena,
+ * pinned buffers and histogram pool have their final size before a caller starts a clock. */
+/* MSQ_PIPE_TRACE=1: every step's host-side timeline (ms since the run started) on stderr after the run */
+typedef struct { int step, t; double sub0, sub1, col0, col1, mrg1; float gpu_ms; } pipe_trace_t;
+#define PIPE_TRACE_MAX 4096
+static double pipe_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+
+struct msq_pipeline {
+    int nthreads, nctx;
+    int trace_on; double t_run0; pipe_trace_t *trace; int ntrace;
     pthread_t th[64];
-    for (int t = 0; t < nthreads; t++) {
-        jobs[t] = (pipe_job_t){ctxs[t], preps, nprep, first, count, t, nthreads, 0, 0};
-        if (nthreads > 1) pthread_create(&th[t], NULL, pipe_worker, &jobs[t]);
+    pthread_mutex_t mu; pthread_cond_t go, done;
+    unsigned gen; int pending, quit;
+    /* thread t owns contexts 2t and 2t + 1 (the last thread only one when nctx is odd): while it decodes and
+     * merges one batch, its next one is already queued on the GPU */
+    mgpu_ctx_t *ctx[128];
+    /* the current run */
+    const msq_prepared_t *const *preps; int nprep, first, count, every;
+    long hits[64]; int rc[64];
+    char err[256];
+};
+typedef struct { msq_pipeline_t *p; int t; } pipe_arg_t;
+
+static void pipe_fail(msq_pipeline_t *p, int t, int rc) {
+    /* mgpu_last_error is per thread: keep this thread's message for the caller */
+    pthread_mutex_lock(&p->mu);
+    if (!p->err[0]) snprintf(p->err, sizeof(p->err), "%s", mgpu_last_error());
+    pthread_mutex_unlock(&p->mu);
+    p->rc[t] = rc;
+}
+
+/* wait for the batch in flight on ctx, merge it (form_result) */
+static int pipe_collect(msq_pipeline_t *p, int t, mgpu_ctx_t *ctx, const msq_prepared_t *pp, pipe_trace_t *tr) {
+    m_sqresult_t *outs = calloc((size_t)(pp->n ? pp->n : 1), sizeof(m_sqresult_t));
+    if (!outs) { p->rc[t] = -1; return -1; }
+    if (tr) tr->col0 = pipe_now() - p->t_run0;
+    int rc = msq_collect_prepared(ctx, pp, outs);
+    if (tr) { tr->col1 = pipe_now() - p->t_run0; mgpu_last_timing(ctx, &tr->gpu_ms, NULL); }
+    if (!rc) p->hits[t] += m_form_result_batch((const m_query_t *const *)pp->queries, outs, pp->nq, pp->num_shards, NULL, 0);
+    m_sqresult_free_batch(outs, pp->n);
+    free(outs);
+    if (tr) {
+        tr->mrg1 = pipe_now() - p->t_run0;
+        pthread_mutex_lock(&p->mu);
+        if (p->ntrace < PIPE_TRACE_MAX) p->trace[p->ntrace++] = *tr;
+        pthread_mutex_unlock(&p->mu);
     }
-    if (nthreads == 1) pipe_worker(&jobs[0]);
+    if (rc) pipe_fail(p, t, rc);
+    return rc;
+}
+
+static void pipe_steps(msq_pipeline_t *p, int t) {
+    p->hits[t] = 0; p->rc[t] = 0;
+    mgpu_ctx_t *cx[2] = { p->ctx[2 * t], (2 * t + 1 < p->nctx) ? p->ctx[2 * t + 1] : NULL };
+    const int ncx = cx[1] ? 2 : 1;
+    if (p->every) {
+        /* warm-up run: every context of this thread takes every batch once */
+        for (int k = 0; k < ncx; k++)
+            for (int i = 0; i < p->count; i++) {
+                const msq_prepared_t *pp = p->preps[(p->first + i) % p->nprep];
+                int rc = msq_submit_prepared(cx[k], pp);
+                if (rc) { pipe_fail(p, t, rc); return; }
+                if (pipe_collect(p, t, cx[k], pp, NULL)) return;
+            }
+        return;
+    }
+    /* steps t, t + nthreads, ...: the next step is submitted before the current one is collected */
+    const msq_prepared_t *inflight[2] = { NULL, NULL };
+    pipe_trace_t tr[2];
+    int slot = 0;
+    for (int i = t; i < p->count || inflight[0] || inflight[1]; i += p->nthreads) {
+        if (i < p->count) {
+            const msq_prepared_t *pp = p->preps[(p->first + i) % p->nprep];
+            tr[slot].step = i; tr[slot].t = t; tr[slot].sub0 = pipe_now() - p->t_run0;
+            int rc = msq_submit_prepared(cx[slot], pp);
+            tr[slot].sub1 = pipe_now() - p->t_run0;
+            if (rc) { pipe_fail(p, t, rc); break; }
+            inflight[slot] = pp;
+        }
+        /* collect the older batch: the other slot when there are two, else this one */
+        const int older = ncx == 2 ? slot ^ 1 : slot;
+        if (inflight[older]) {
+            const msq_prepared_t *pp = inflight[older];
+            inflight[older] = NULL;
+            if (pipe_collect(p, t, cx[older], pp, p->trace_on ? &tr[older] : NULL)) break;
+        }
+        if (ncx == 2) slot ^= 1;
+    }
+    /* after a failure: drain what is still in flight so that the contexts stay usable */
+    for (int k = 0; k < ncx; k++) if (inflight[k]) {
+        m_sqresult_t *outs = calloc((size_t)(inflight[k]->n ? inflight[k]->n : 1), sizeof(m_sqresult_t));
+        if (outs) { msq_collect_prepared(cx[k], inflight[k], outs); m_sqresult_free_batch(outs, inflight[k]->n); free(outs); }
+    }
+}
+
+static void *pipe_thread(void *arg) {
+    pipe_arg_t *a = arg;
+    msq_pipeline_t *p = a->p; const int t = a->t;
+    free(a);
+    unsigned seen = 0;
+    for (;;) {
+        pthread_mutex_lock(&p->mu);
+        while (p->gen == seen && !p->quit) pthread_cond_wait(&p->go, &p->mu);
+        if (p->quit) { pthread_mutex_unlock(&p->mu); return NULL; }
+        seen = p->gen;
+        pthread_mutex_unlock(&p->mu);
+        pipe_steps(p, t);
+        pthread_mutex_lock(&p->mu);
+        if (--p->pending == 0) pthread_cond_signal(&p->done);
+        pthread_mutex_unlock(&p->mu);
+    }
+}
+
+int msq_pipeline_create(mgpu_ctx_t *const *ctxs, int nctx, msq_pipeline_t **out) {
+    if (!ctxs || !out || nctx < 1 || nctx > 128) return MGPU_E_ARG;
+    msq_pipeline_t *p = calloc(1, sizeof(*p));
+    if (!p) return -1;
+    const int nthreads = (nctx + 1) / 2;
+    p->nthreads = nthreads; p->nctx = nctx;
+    p->trace_on = getenv("MSQ_PIPE_TRACE") != NULL;
+    if (p->trace_on) p->trace = calloc(PIPE_TRACE_MAX, sizeof(pipe_trace_t));
+    pthread_mutex_init(&p->mu, NULL); pthread_cond_init(&p->go, NULL); pthread_cond_init(&p->done, NULL);
+    for (int t = 0; t < nctx; t++) p->ctx[t] = ctxs[t];
+    for (int t = 0; t < nthreads; t++) {
+        pipe_arg_t *a = malloc(sizeof(*a));
+        a->p = p; a->t = t;
+        if (pthread_create(&p->th[t], NULL, pipe_thread, a)) { free(a); p->nthreads = t; msq_pipeline_destroy(p); return -1; }
+    }
+    *out = p;
+    return 0;
+}
+
+static int pipe_dispatch(msq_pipeline_t *p, const msq_prepared_t *const *preps, int nprep, int first, int count,
+                         int every, long *hits_out) {
+    if (!p || !preps || nprep < 1 || count < 0) return MGPU_E_ARG;
+    pthread_mutex_lock(&p->mu);
+    p->preps = preps; p->nprep = nprep; p->first = first; p->count = count; p->every = every;
+    p->err[0] = 0;
+    p->ntrace = 0; p->t_run0 = pipe_now();
+    p->pending = p->nthreads;
+    p->gen++;
+    pthread_cond_broadcast(&p->go);
+    while (p->pending) pthread_cond_wait(&p->done, &p->mu);
+    pthread_mutex_unlock(&p->mu);
     long hits = 0; int rc = 0;
-    for (int t = 0; t < nthreads; t++) {
-        if (nthreads > 1) pthread_join(th[t], NULL);
-        hits += jobs[t].hits;
-        if (jobs[t].rc && !rc) rc = jobs[t].rc;
-    }
+    for (int t = 0; t < p->nthreads; t++) { hits += p->hits[t]; if (p->rc[t] && !rc) rc = p->rc[t]; }
     if (hits_out) *hits_out = hits;
+    if (p->trace_on && !every) {
+        fprintf(stderr, "[pipe] run of %d steps took %.3f ms\n", count, pipe_now() - p->t_run0);
+        for (int i = 0; i < p->ntrace; i++) {
+            const pipe_trace_t *x = &p->trace[i];
+            fprintf(stderr, "[pipe] step %3d thr %d submit %.3f-%.3f collect %.3f-%.3f merged %.3f gpu %.3f\n",
+                    x->step, x->t, x->sub0, x->sub1, x->col0, x->col1, x->mrg1, x->gpu_ms);
+        }
+    }
+    return rc;
+}
+
+int msq_pipeline_run(msq_pipeline_t *p, const msq_prepared_t *const *preps, int nprep, int first, int count, long *hits_out) {
+    return pipe_dispatch(p, preps, nprep, first, count, 0, hits_out);
+}
+
+int msq_pipeline_warm(msq_pipeline_t *p, const msq_prepared_t *const *preps, int nprep) {
+    return pipe_dispatch(p, preps, nprep, 0, nprep, 1, NULL);
+}
+
+const char *msq_pipeline_error(const msq_pipeline_t *p) { return p ? p->err : ""; }
+
+void msq_pipeline_destroy(msq_pipeline_t *p) {
+    if (!p) return;
+    pthread_mutex_lock(&p->mu);
+    p->quit = 1;
+    pthread_cond_broadcast(&p->go);
+    pthread_mutex_unlock(&p->mu);
+    for (int t = 0; t < p->nthreads; t++) pthread_join(p->th[t], NULL);
+    pthread_mutex_destroy(&p->mu); pthread_cond_destroy(&p->go); pthread_cond_destroy(&p->done);
+    free(p->trace);
+    free(p);
+}
+
+/* one-shot form: threads created, run, joined */
+int msq_run_pipeline(mgpu_ctx_t *const *ctxs, int nctx, const msq_prepared_t *const *preps, int nprep,
+                     int first, int count, long *hits_out) {
+    msq_pipeline_t *p = NULL;
+    int rc = msq_pipeline_create(ctxs, nctx, &p);
+    if (rc) return rc;
+    rc = msq_pipeline_run(p, preps, nprep, first, count, hits_out);
+    msq_pipeline_destroy(p);
     return rc;
 }

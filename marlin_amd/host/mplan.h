@@ -60,11 +60,25 @@ typedef struct msq_prepared msq_prepared_t;
 int  msq_prepare_batch(mmirror_t *const *mirrors, int num_shards, const m_query_t *const *queries,
                        int nq, int capture, msq_prepared_t **out);
 int  msq_execute_prepared(mgpu_ctx_t *ctx, const msq_prepared_t *pp, m_sqresult_t *outs);
+/* execute_prepared in two halves (one batch in flight per context): submit enqueues the GPU work and returns,
+ * collect waits for it and decodes; pp must stay alive in between */
+int  msq_submit_prepared(mgpu_ctx_t *ctx, const msq_prepared_t *pp);
+int  msq_collect_prepared(mgpu_ctx_t *ctx, const msq_prepared_t *pp, m_sqresult_t *outs);
 void msq_prepared_free(msq_prepared_t *pp);
-/* serving loop: nthreads host threads (one context each) keep that many prepared batches in flight;
- * step i runs batch (first + i) % nprep through execute_prepared + form_result (mplan.c) */
-int  msq_run_pipeline(mgpu_ctx_t *const *ctxs, int nthreads, const msq_prepared_t *const *preps, int nprep,
+/* serving loop: nctx contexts = nctx batches in flight, two contexts per host thread (a thread submits its next
+ * batch before it decodes and merges the current one); step i runs batch (first + i) % nprep through
+ * submit / collect + form_result (mplan.c) */
+int  msq_run_pipeline(mgpu_ctx_t *const *ctxs, int nctx, const msq_prepared_t *const *preps, int nprep,
                       int first, int count, long *hits_out);
+/* the same loop with its threads kept between runs (created once, parked on a condition variable):
+ * create -> warm (every batch through every context once: first-use allocations) -> run ... -> destroy.
+ * msq_pipeline_error: message of the first failed step of the last run (worker threads' own error text). */
+typedef struct msq_pipeline msq_pipeline_t;
+int  msq_pipeline_create(mgpu_ctx_t *const *ctxs, int nctx, msq_pipeline_t **out);
+int  msq_pipeline_warm(msq_pipeline_t *p, const msq_prepared_t *const *preps, int nprep);
+int  msq_pipeline_run(msq_pipeline_t *p, const msq_prepared_t *const *preps, int nprep, int first, int count, long *hits_out);
+const char *msq_pipeline_error(const msq_pipeline_t *p);
+void msq_pipeline_destroy(msq_pipeline_t *p);
 
 /* host threads used for plan building inside msq_execute_batch (default 1) */
 void msq_set_plan_threads(int n);
