@@ -196,6 +196,18 @@ int mgpu_posting_op(mgpu_ctx_t *c, mgpu_shard_t *s, int op, uint32_t pid_a, uint
                     uint64_t *out_words, uint32_t nwords, uint64_t *card);
 
 
+/* mgpu_posting_op for callers that cannot allocate.  No counterpart in the reference: it exists for callers
+ * that may not call hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid it.
+ * Same arguments, results and error codes as mgpu_posting_op; its scratch (two operand rows, the result row, the
+ * cardinality word) is a static device array of 3 * MGPU_NOALLOC_MAX_DOCS / 8 + 256 bytes (6 MiB + 256 B) that
+ * every GPU the library runs on holds until the process ends.  Shards with more than MGPU_NOALLOC_MAX_DOCS docids
+ * are refused with MGPU_E_LIMIT.  The call allocates nothing (device, pinned or heap); the context's set-up
+ * (mgpu_ctx_create) looked up the array's device address and pinned the result bounce buffer.  All calls on one
+ * GPU share that GPU's array: calls that overlap on one GPU race, serialise them. */
+#define MGPU_NOALLOC_MAX_DOCS (16u << 20)
+int mgpu_posting_op_noalloc(mgpu_ctx_t *c, mgpu_shard_t *s, int op, uint32_t pid_a, uint32_t pid_b,
+                            uint64_t *out_words, uint32_t nwords, uint64_t *card);
+
 #ifdef __cplusplus
 }
 #endif

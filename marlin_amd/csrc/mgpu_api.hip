@@ -13,6 +13,7 @@
 #include <cstring>
 #include <string>
 #include <memory>
+#include <mutex>
 #include <vector>
 #include "mgpu_types.h"
 
@@ -34,9 +35,19 @@ void mgk_select(hipStream_t st, const SelJob *jobs, const void *outs, uint32_t n
                 void *items_mem, uint32_t cap_items, uint32_t *counters, uint32_t *fin_list);
 void mgk_row_op(hipStream_t st, const unsigned long long *a, const unsigned long long *b, unsigned long long *out,
                 uint32_t W, int op, unsigned long long *card);
+void mgk_scatter_list(hipStream_t st, const uint32_t *src, uint64_t n, unsigned long long *dst);
 void mgk_fetch(hipStream_t st, void *dst, const void *src_pinned, size_t bytes);
 }
 
+// Scratch of mgpu_posting_op_noalloc (include/marlin_gpu.h): two operand rows, the result row and the cardinality
+// word, in device memory that comes with the code object instead of from hipMalloc.  In host code this name is
+// only a handle: the device address is looked up once per device (noalloc_scratch_of) and every use below goes
+// through that pointer.  Each GPU the library runs on holds its own copy until the process ends.
+#define NA_ROW_BYTES ((size_t)MGPU_NOALLOC_MAX_DOCS / 8)
+#define NA_SCRATCH_BYTES (3 * NA_ROW_BYTES + 256)
+static __device__ __align__(256) unsigned char g_noalloc_scratch[NA_SCRATCH_BYTES];
+#define NA_MAX_DEVICES 64
+static char *g_na_ptr[NA_MAX_DEVICES];
 
 struct FkJob { const uint32_t *hist; const uint32_t *ord2id; const uint32_t *touched; const uint32_t *ntouched;
                u64 *key_hi, *key_lo; u64 *andor; };
@@ -328,6 +339,8 @@ struct mgpu_ctx {
     // select passes); a batch that does not run to its end leaves `cln_dirty` set and the next one clears it.
     Arena cln; bool cln_dirty = true;
     uint32_t *pool_used = nullptr;
+    char *na_scratch = nullptr;                        // this device's g_noalloc_scratch (mgpu_posting_op_noalloc)
+    char *na_pin = nullptr;                            // pinned bounce buffer of that entry point: [card 256 B | one row]
     struct Pending *pend = nullptr;                    // the batch in flight (execute_begin .. execute_end)
     hipEvent_t ev[MGPU_NUM_STAGES + 1];
     int profiling;
@@ -349,6 +362,20 @@ extern "C" int mgpu_ctx_create(int device, uint64_t scratch_bytes, mgpu_ctx_t **
     HIPCHK(hipMalloc((void **)&c->pool, c->pool_cap * 8));
     HIPCHK(hipMalloc((void **)&c->pool_used, 256));
     for (int i = 0; i <= MGPU_NUM_STAGES; i++) HIPCHK(hipEventCreate(&c->ev[i]));
+    // set-up of the allocation-free entry point: this device's address of the static scratch array (each GPU has
+    // its own copy at its own address) and a pinned bounce buffer for its results
+    if (device < 0 || device >= NA_MAX_DEVICES) return fail(MGPU_E_LIMIT, "device index above 63");
+    {
+        static std::mutex mu;
+        std::lock_guard<std::mutex> lk(mu);
+        if (!g_na_ptr[device]) {
+            void *ptr = nullptr;
+            HIPCHK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_noalloc_scratch)));
+            g_na_ptr[device] = (char *)ptr;
+        }
+    }
+    c->na_scratch = g_na_ptr[device];
+    HIPCHK(hipHostMalloc((void **)&c->na_pin, NA_ROW_BYTES + 256, hipHostMallocDefault));
     *out = c;
     return MGPU_OK;
 }
@@ -363,6 +390,7 @@ extern "C" void mgpu_ctx_destroy(mgpu_ctx_t *c) {
     if (c->cln.dev) (void)hipFree(c->cln.dev);
     if (c->pin) (void)hipHostFree(c->pin);
     if (c->pin_out) (void)hipHostFree(c->pin_out);
+    if (c->na_pin) (void)hipHostFree(c->na_pin);
     (void)hipFree(c->pool); (void)hipFree(c->pool_used);
     for (int i = 0; i <= MGPU_NUM_STAGES; i++) (void)hipEventDestroy(c->ev[i]);
     (void)hipStreamDestroy(c->stream);
@@ -1320,5 +1348,51 @@ extern "C" int mgpu_posting_op(mgpu_ctx_t *c, mgpu_shard_t *s, int op, uint32_t 
     }
     HIPCHK(hipStreamSynchronize(st));
     if (card) *card = hc;
+    return MGPU_OK;
+}
+
+// The same operation for callers that cannot allocate (HIP graph capture around it, serving loops and harnesses
+// that forbid hipMalloc).  No hipMalloc / hipFree / hipHostMalloc and no host heap use in here: the operand rows,
+// the result row and the cardinality word live in this device's copy of g_noalloc_scratch (address looked up at
+// mgpu_ctx_create), sparse postings are scattered by a kernel that takes the list as its arguments (no item table
+// to upload), and results come back through the context's pinned bounce buffer.  Every call on a GPU shares that
+// GPU's scratch array, which still holds the previous call's rows: the regions a call accumulates into (scattered
+// operand rows, the cardinality word) are cleared first, the result row is written whole.  Calls that overlap on one
+// GPU (two contexts, two threads) race on it.
+extern "C" int mgpu_posting_op_noalloc(mgpu_ctx_t *c, mgpu_shard_t *s, int op, uint32_t pid_a, uint32_t pid_b,
+                                       uint64_t *out_words, uint32_t nwords, uint64_t *card) {
+    if (!c || !s || op < 0 || op > 2) return fail(MGPU_E_ARG, "bad argument");
+    if (pid_a >= s->dev.num_postings || pid_b >= s->dev.num_postings) return fail(MGPU_E_ARG, "posting id out of range");
+    if (s->device != c->device) return fail(MGPU_E_ARG, "shard not on the context's device");
+    const ShardDev &sd = s->dev;
+    const size_t rowb = (size_t)sd.Wp * 8;
+    if (rowb > NA_ROW_BYTES)
+        return fail(MGPU_E_LIMIT, "mgpu_posting_op_noalloc: shard has more than MGPU_NOALLOC_MAX_DOCS docids (static scratch holds three rows of that size)");
+    if (out_words && nwords < sd.W) return fail(MGPU_E_ARG, "output buffer too small");
+    if (!c->na_scratch || !c->na_pin) return fail(MGPU_E_HIP, "context has no static scratch (mgpu_ctx_create did not finish)");
+    HIPCHK(hipSetDevice(c->device));
+    char *S = c->na_scratch;                                    // the device address, never the array's name
+    u64 *ra = (u64 *)S, *rb = (u64 *)(S + NA_ROW_BYTES), *ro = (u64 *)(S + 2 * NA_ROW_BYTES);
+    unsigned long long *dcard = (unsigned long long *)(S + 3 * NA_ROW_BYTES);
+    hipStream_t st = c->stream;
+    HIPCHK(hipMemsetAsync(dcard, 0, 256, st));
+    const u64 *src[2] = {nullptr, nullptr};
+    const uint32_t pids[2] = {pid_a, pid_b};
+    u64 *rows[2] = {ra, rb};
+    for (int i = 0; i < 2; i++) {
+        const int32_t di = s->post_dense[pids[i]];
+        if (di >= 0) { src[i] = (const u64 *)sd.dense + (size_t)di * sd.Wp; continue; }
+        src[i] = rows[i];
+        HIPCHK(hipMemsetAsync(rows[i], 0, rowb, st));           // last call's row is still there
+        const uint64_t cnt = s->post_off[pids[i] + 1] - s->post_off[pids[i]];
+        mgk_scatter_list(st, sd.post_doc + s->post_off[pids[i]], cnt, (unsigned long long *)rows[i]);
+    }
+    mgk_row_op(st, src[0], src[1], ro, sd.W, op, dcard);
+    HIPCHK(hipMemcpyAsync(c->na_pin, dcard, 8, hipMemcpyDeviceToHost, st));
+    if (out_words) HIPCHK(hipMemcpyAsync(c->na_pin + 256, ro, (size_t)sd.W * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    if (card) memcpy(card, c->na_pin, 8);
+    if (out_words) memcpy(out_words, c->na_pin + 256, (size_t)sd.W * 8);
     return MGPU_OK;
 }

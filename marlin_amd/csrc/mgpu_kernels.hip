@@ -90,6 +90,16 @@ __global__ __launch_bounds__(MG_BLOCK) void k_scatter(const ScatterItem *items, 
         scatter_chunk(s.src, s.n, (u64 *)s.dst);
     }
 }
+// the same for ONE list named by the kernel arguments (no item table to upload): chunks of MG_SCATTER_CHUNK docids
+__global__ __launch_bounds__(MG_BLOCK) void k_scatter_list(const uint32_t *src, uint64_t n, u64 *dst) {
+    const uint64_t nchunks = (n + MG_SCATTER_CHUNK - 1) / MG_SCATTER_CHUNK;
+    for (uint64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const uint64_t at = c * MG_SCATTER_CHUNK;
+        const uint64_t left = n - at;
+        scatter_chunk(src + at, (uint32_t)(left < MG_SCATTER_CHUNK ? left : MG_SCATTER_CHUNK), dst);
+    }
+}
+
 // ------------------------------------------------------------------ formula + filter + popcount
 // get_matching_docids (squery.c:212-277) fused with squery_apply_filters (squery.c:377-395,
 // filter_apply.c:207-227) and bmap_cardinality (bmap.c:362-368).
@@ -1884,6 +1894,11 @@ void mgk_fetch(hipStream_t st, void *dst, const void *src_pinned, size_t bytes) 
     if (!n16) return;
     size_t g = (n16 + MG_BLOCK - 1) / MG_BLOCK; if (g > 128) g = 128;
     hipLaunchKernelGGL(k_fetch, dim3((uint32_t)g), dim3(MG_BLOCK), 0, st, (uint4 *)dst, (const uint4 *)src_pinned, n16);
+}
+void mgk_scatter_list(hipStream_t st, const uint32_t *src, uint64_t n, unsigned long long *dst) {
+    if (!n) return;
+    const uint64_t nchunks = (n + MG_SCATTER_CHUNK - 1) / MG_SCATTER_CHUNK;
+    hipLaunchKernelGGL(k_scatter_list, dim3((uint32_t)(nchunks < 8192 ? nchunks : 8192)), dim3(MG_BLOCK), 0, st, src, n, (u64 *)dst);
 }
 // number of workgroups of the persistent kernels that stride over the tile work list
 static uint32_t worklist_grid(uint32_t tile_cap) {

@@ -185,6 +185,7 @@ def load():
         "mgpu_stage_name": (C.c_char_p, [ci]),
         "mgpu_shard_bytes": (C.c_uint64, [vp]),
         "mgpu_posting_op": (ci, [vp, vp, ci, cu, cu, C.POINTER(C.c_uint64), cu, C.POINTER(C.c_uint64)]),
+        "mgpu_posting_op_noalloc": (ci, [vp, vp, ci, cu, cu, C.POINTER(C.c_uint64), cu, C.POINTER(C.c_uint64)]),
         "mshard_wid_posting": (C.c_uint64, [vp, cu, C.POINTER(C.POINTER(cu))]),
     }
     for name, (res, args) in sigs.items():
