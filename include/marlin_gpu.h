@@ -50,10 +50,25 @@ const char *mgpu_last_error(void);
 int mgpu_device_count(void);
 
 /* ---------------------------------------------------------------- mirror ------------------
- * Source formats: the sets stored by mbmap (mbmap.c:253-283 header + container keys), the
+ * Source formats: the sets stored by mbmap (mbmap.c:253-283 header + container keys; read as stored through
+ * post_mbmap / mgpu_mbmap_decode, or pre-expanded to docid lists by the caller), the
  * docid2data blob (sindex.c:273-326, 409-496) and num_dbi (sindex.c:528-535).  All arrays are
  * host memory, copied during the call.  Posting ids ("pid") are chosen by the caller; pid 0 is
  * reserved for "all used docids" (shard_get_all_docids, shard.c:51-53). */
+/* One posting exactly as mbmap stores it in LMDB (mbmap.c:183-283): `header` is the value at key id,
+ * [u16 num_c][u16 cid x num_c]; cont[i] is the value at key id + cid_i + 1, a container buffer
+ * [u16 id][u16 card][payload]: card ascending u16 values when card <= 4096 (CUTOFF, cont.h:8, cont.c:118-130), else
+ * 1024 little-endian u64 bitset words (BCUTOFF); a full container is stored as card = 0 with payload[0] = 0xFFFF
+ * (cont_cardinality, cont.c:543-548).  A NULL cont[i] is a container whose mdb_get failed (mbmap.c:276-278): skipped. */
+typedef struct mgpu_mbmap {
+    const uint8_t *header; uint32_t header_len;
+    const uint8_t *const *cont; const uint32_t *cont_len;      /* [num_c] */
+} mgpu_mbmap_t;
+/* bmap_iterate (bmap.c:370-374, cont.c:590-610) over such a posting: ascending docids into out[0..cap), *n = its
+ * cardinality.  Host code only (no GPU needed).  MGPU_E_ARG for a malformed value, MGPU_E_LIMIT when cap is too small
+ * (*n is still set; out may be NULL with cap 0 to ask for the size). */
+int mgpu_mbmap_decode(const mgpu_mbmap_t *b, uint32_t *out, uint64_t cap, uint64_t *n);
+
 typedef struct mgpu_shard_desc {
     uint32_t max_docid;                 /* docids 1..max_docid */
     int      num_numbers, num_facets;
@@ -61,6 +76,9 @@ typedef struct mgpu_shard_desc {
     uint32_t        num_postings;       /* pids 0..num_postings-1 */
     const uint64_t *post_off;           /* [num_postings + 1] */
     const uint32_t *post_doc;
+    /* ... or, instead, every posting in the reference's own stored form: [num_postings] entries (an entry with a NULL
+     * header is an absent key = empty posting); when set, post_off / post_doc are ignored */
+    const mgpu_mbmap_t *post_mbmap;
     /* docid2data, raw blobs in the reference layout */
     const uint64_t *dd_off;             /* [max_docid + 2], blob of doc d = dd[dd_off[d], dd_off[d+1]) */
     const uint8_t  *dd;

@@ -102,6 +102,67 @@ static inline const uint8_t *rd_vint(const uint8_t *buf, int *value) {   // read
     return buf;
 }
 
+// ------------------------------------------------------------------ mbmap format (mbmap.c:183-283, cont.c)
+static inline uint16_t rd16(const uint8_t *p) { uint16_t v; memcpy(&v, p, 2); return v; }
+// walks one stored posting; emit(docid) in ascending order.  Returns MGPU_OK / MGPU_E_ARG.
+template <class F>
+static int mbmap_walk(const mgpu_mbmap_t *b, F emit, uint64_t *count) {
+    *count = 0;
+    if (!b || !b->header) return MGPU_OK;                    // absent key: mbmap_load_bmap returns NULL, an empty set
+    if (b->header_len < 2) return fail(MGPU_E_ARG, "mbmap header shorter than its count");
+    const uint32_t num_c = rd16(b->header);
+    if ((uint64_t)b->header_len < 2 + 2 * (uint64_t)num_c) return fail(MGPU_E_ARG, "mbmap header shorter than its container list");
+    if (num_c && (!b->cont || !b->cont_len)) return fail(MGPU_E_ARG, "mbmap containers missing");
+    int64_t prev_cid = -1;
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < num_c; i++) {
+        const uint32_t cid = rd16(b->header + 2 + 2 * i);
+        if ((int64_t)cid <= prev_cid) return fail(MGPU_E_ARG, "mbmap container ids not ascending");
+        prev_cid = cid;
+        const uint8_t *c = b->cont[i];
+        if (!c) continue;                                    // mdb_get failed in the reference: container skipped
+        const uint32_t len = b->cont_len[i];
+        if (len < 4) return fail(MGPU_E_ARG, "mbmap container shorter than its header");
+        if (rd16(c) != cid) return fail(MGPU_E_ARG, "mbmap container id does not match its key");
+        uint32_t card = rd16(c + 2);
+        const uint32_t base = cid << 16;
+        // cont_cardinality (cont.c:543-548): card 0 with a first payload word of 0xFFFF is the full container
+        if (card == 0 && len >= 6 && rd16(c + 4) == 0xFFFF) card = 65536;
+        if (card <= 4096) {                                  // array container (cont_is_array, cont.c:118-123)
+            if ((uint64_t)len < 4 + 2 * (uint64_t)card) return fail(MGPU_E_ARG, "mbmap array container shorter than its cardinality");
+            int32_t prev = -1;
+            for (uint32_t j = 0; j < card; j++) {
+                const uint32_t v = rd16(c + 4 + 2 * j);
+                if ((int32_t)v <= prev) return fail(MGPU_E_ARG, "mbmap array container not ascending");
+                prev = (int32_t)v;
+                emit(base + v);
+            }
+            total += card;
+        } else {                                             // bitset container: 1024 u64 words from byte 4 (unaligned)
+            if (len < 4 + 8192) return fail(MGPU_E_ARG, "mbmap bitset container shorter than 8192 bytes");
+            uint64_t seen = 0;
+            for (uint32_t w = 0; w < 1024; w++) {
+                uint64_t x; memcpy(&x, c + 4 + 8 * (size_t)w, 8);
+                seen += (uint64_t)__builtin_popcountll(x);
+                while (x) { const int r = __builtin_ctzll(x); x &= x - 1; emit(base + 64 * w + (uint32_t)r); }
+            }
+            if (seen != card) return fail(MGPU_E_ARG, "mbmap bitset container cardinality does not match its bits");
+            total += seen;
+        }
+    }
+    *count = total;
+    return MGPU_OK;
+}
+
+extern "C" int mgpu_mbmap_decode(const mgpu_mbmap_t *b, uint32_t *out, uint64_t cap, uint64_t *n) {
+    uint64_t at = 0, cnt = 0;
+    const int rc = mbmap_walk(b, [&](uint32_t d) { if (at < cap && out) out[at] = d; at++; }, &cnt);
+    if (n) *n = rc ? 0 : cnt;
+    if (rc) return rc;
+    if (cnt > cap) return fail(MGPU_E_LIMIT, "mgpu_mbmap_decode: output buffer smaller than the posting");
+    return MGPU_OK;
+}
+
 extern "C" void mgpu_shard_destroy(mgpu_shard_t *s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
@@ -111,8 +172,26 @@ extern "C" void mgpu_shard_destroy(mgpu_shard_t *s) {
 
 extern "C" uint64_t mgpu_shard_bytes(const mgpu_shard_t *s) { return s ? s->bytes : 0; }
 
+static int shard_create_impl(int device, const mgpu_shard_desc_t *d, mgpu_shard_t **out);
 extern "C" int mgpu_shard_create(int device, const mgpu_shard_desc_t *d, mgpu_shard_t **out) {
     if (!d || !out) return fail(MGPU_E_ARG, "null argument");
+    if (!d->post_mbmap) return shard_create_impl(device, d, out);
+    // postings handed over as stored (mbmap header + containers): expand them here (mbmap_load_bmap + bmap_iterate)
+    std::vector<uint64_t> off((size_t)d->num_postings + 1, 0);
+    std::vector<uint32_t> doc;
+    for (uint32_t p = 0; p < d->num_postings; p++) {
+        off[p] = doc.size();
+        uint64_t cnt = 0;
+        const int rc = mbmap_walk(&d->post_mbmap[p], [&](uint32_t x) { doc.push_back(x); }, &cnt);
+        if (rc) return rc;
+    }
+    off[d->num_postings] = doc.size();
+    if (doc.empty()) doc.push_back(0);
+    mgpu_shard_desc_t d2 = *d;
+    d2.post_mbmap = nullptr; d2.post_off = off.data(); d2.post_doc = doc.data();
+    return shard_create_impl(device, &d2, out);
+}
+static int shard_create_impl(int device, const mgpu_shard_desc_t *d, mgpu_shard_t **out) {
     if (d->num_numbers > MGPU_MAX_FIELDS || d->num_facets > MGPU_MAX_FIELDS)
         return fail(MGPU_E_LIMIT, "more than 32 numeric or facet fields");
     HIPCHK(hipSetDevice(device));

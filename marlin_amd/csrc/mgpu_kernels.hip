@@ -1858,17 +1858,18 @@ extern "C" {
 int mgk_debug_clock_cal(unsigned long long *out3) {
     unsigned long long *d = nullptr;
     if (hipMalloc(&d, 16) != hipSuccess) return -1;
-    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipFree(d); return -1; }
     hipLaunchKernelGGL(k_clock_cal, dim3(1), dim3(1), 0, 0, d);      // warm
-    hipEventRecord(e0, 0);
+    (void)hipEventRecord(e0, 0);
     hipLaunchKernelGGL(k_clock_cal, dim3(1), dim3(1), 0, 0, d);
-    hipEventRecord(e1, 0);
-    hipEventSynchronize(e1);
-    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
-    hipMemcpy(out3, d, 16, hipMemcpyDeviceToHost);
+    (void)hipEventRecord(e1, 0);
+    float ms = 0;
+    const bool ok = hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess &&
+                    hipMemcpy(out3, d, 16, hipMemcpyDeviceToHost) == hipSuccess;
     out3[2] = (unsigned long long)(ms * 1e6);
-    hipFree(d); hipEventDestroy(e0); hipEventDestroy(e1);
-    return 0;
+    (void)hipFree(d); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return ok ? 0 : -1;
 }
 // phase clocks: enable, and read + reset the 16 accumulators (100 MHz wall_clock64 ticks)
 int mgk_debug_phases(int on, unsigned long long *out16) {

@@ -107,6 +107,44 @@ class ShardStruct(C.Structure):
                 ("num_bools", C.c_int), ("num_facets", C.c_int)]
 
 
+class Mbmap(C.Structure):
+    """mgpu_mbmap_t (include/marlin_gpu.h): one posting as mbmap stores it"""
+    _fields_ = [("header", C.POINTER(C.c_uint8)), ("header_len", C.c_uint32),
+                ("cont", C.POINTER(C.POINTER(C.c_uint8))), ("cont_len", C.POINTER(C.c_uint32))]
+
+
+class ShardDesc(C.Structure):
+    """mgpu_shard_desc_t (include/marlin_gpu.h)"""
+    _fields_ = [("max_docid", C.c_uint32), ("num_numbers", C.c_int), ("num_facets", C.c_int),
+                ("num_postings", C.c_uint32), ("post_off", C.POINTER(C.c_uint64)), ("post_doc", C.POINTER(C.c_uint32)),
+                ("post_mbmap", C.POINTER(Mbmap)),
+                ("dd_off", C.POINTER(C.c_uint64)), ("dd", C.POINTER(C.c_uint8)),
+                ("np_n", C.c_uint64 * M_MAX_FIELDS), ("np_doc", C.POINTER(C.c_uint32) * M_MAX_FIELDS)]
+
+
+def make_mbmap(header, containers):
+    """bytes (or None) + list of bytes -> (Mbmap, keepalive): the ctypes buffers must outlive the struct's use"""
+    keep = []
+    m = Mbmap()
+    if header is None:
+        return m, keep
+    hb = (C.c_uint8 * len(header)).from_buffer_copy(header)
+    keep.append(hb)
+    m.header = C.cast(hb, C.POINTER(C.c_uint8)); m.header_len = len(header)
+    n = len(containers)
+    ptrs = (C.POINTER(C.c_uint8) * max(n, 1))()
+    lens = (C.c_uint32 * max(n, 1))()
+    for i, c in enumerate(containers):
+        if c is None:
+            continue
+        cb = (C.c_uint8 * len(c)).from_buffer_copy(c)
+        keep.append(cb)
+        ptrs[i] = C.cast(cb, C.POINTER(C.c_uint8)); lens[i] = len(c)
+    keep += [ptrs, lens]
+    m.cont = ptrs; m.cont_len = lens
+    return m, keep
+
+
 _lib = None
 
 
@@ -185,6 +223,9 @@ def load():
         "mgpu_stage_name": (C.c_char_p, [ci]),
         "mgpu_shard_bytes": (C.c_uint64, [vp]),
         "mgpu_posting_op": (ci, [vp, vp, ci, cu, cu, C.POINTER(C.c_uint64), cu, C.POINTER(C.c_uint64)]),
+        "mgpu_mbmap_decode": (ci, [C.POINTER(Mbmap), C.POINTER(cu), C.c_uint64, C.POINTER(C.c_uint64)]),
+        "mgpu_shard_create": (ci, [ci, C.POINTER(ShardDesc), C.POINTER(vp)]),
+        "mgpu_shard_destroy": (None, [vp]),
         "mgpu_posting_op_noalloc": (ci, [vp, vp, ci, cu, cu, C.POINTER(C.c_uint64), cu, C.POINTER(C.c_uint64)]),
         "mshard_wid_posting": (C.c_uint64, [vp, cu, C.POINTER(C.POINTER(cu))]),
     }
