@@ -6,7 +6,7 @@ CFLAGS  ?= -O2 -g -std=gnu11 -fPIC -Wall -Wextra -Wno-unused-parameter
 REF     ?= /root/reference
 
 HOST_SRC = marlin_amd/host/mdict.c marlin_amd/host/mshard.c marlin_amd/host/manalyzer.c \
-           marlin_amd/host/mquery.c marlin_amd/host/mplan.c
+           marlin_amd/host/mquery.c marlin_amd/host/mplan.c marlin_amd/host/mbridge.c
 HOST_HDR = $(wildcard marlin_amd/host/*.h) include/marlin_gpu.h
 ORC_SRC  = oracle/orc_squery.c oracle/orc_sort.c
 GPU_SRC  = $(wildcard marlin_amd/csrc/*.hip)
@@ -43,7 +43,18 @@ oracle/_ref/libmarlin_ref.so:
 	    $(REF)/src/main/bmap.c $(REF)/src/main/cont.c $(REF)/src/main/sort.c \
 	    $(REF)/src/main/hashtable.c $(REF)/src/utils/farmhash-c.c -o $@
 
-clean:
-	rm -f marlin_amd/lib/*.so oracle/liborc.so oracle/_ref/*.so
+# The drop-in replacement for the reference's squery.c, compiled against the reference's own headers (same include
+# paths as `ref`).  Build container only; the object never travels and nothing links it here: the check is that it
+# compiles without warnings and exports execute_squery / sqresult_free (tests/test_shim.py).
+shim: shim/_build/squery_gpu.o
+shim/_build/squery_gpu.o: shim/squery_gpu.c $(HOST_HDR)
+	@mkdir -p shim/_build
+	$(CC) -std=gnu99 -O2 -fPIC -Wall -Wextra -Wno-unused-parameter -Wno-sign-compare -Werror -D_GNU_SOURCE -DH2O_USE_LIBUV=0 \
+	    -I$(REF)/src/inc -I$(REF)/src/main -I$(REF)/src/utils -I$(REF)/src/analyzer \
+	    -I$(REF)/deps/jansson/src -I$(REF)/deps/jansson/android -I$(REF)/deps/h2o/include -I$(REF)/deps/lmdb \
+	    -I$(REF)/deps/utf8proc -I$(REF)/deps -Iinclude -Imarlin_amd/host -c shim/squery_gpu.c -o $@
 
-.PHONY: all gpu host oracle ref clean
+clean:
+	rm -f marlin_amd/lib/*.so oracle/liborc.so oracle/_ref/*.so shim/_build/*.o
+
+.PHONY: all gpu host oracle ref shim clean

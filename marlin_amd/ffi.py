@@ -107,6 +107,23 @@ class ShardStruct(C.Structure):
                 ("num_bools", C.c_int), ("num_facets", C.c_int)]
 
 
+class ShardFull(C.Structure):
+    """all of mshard_t (marlin_amd/host/mshard.h), for tests that walk a shard's stored sets"""
+    _P32, _P64 = C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+    _fields_ = [("max_docid", C.c_uint32), ("num_strings", C.c_int), ("num_numbers", C.c_int),
+                ("num_bools", C.c_int), ("num_facets", C.c_int), ("dict", C.c_void_p),
+                ("dd_off", _P64), ("dd", C.POINTER(C.c_uint8)),
+                ("word_count", C.c_uint32), ("wp_off", _P64), ("wp_doc", _P32),
+                ("tword_count", C.c_uint32), ("tp_off", _P64), ("tp_doc", _P32), ("tw_off", _P64), ("tw_wid", _P32),
+                ("nfid", C.c_uint32 * M_MAX_FIELDS), ("fid", _P32 * M_MAX_FIELDS), ("fp_off", _P64 * M_MAX_FIELDS),
+                ("fp_doc", _P32 * M_MAX_FIELDS),
+                ("nfstr", C.c_uint32), ("fstr_id", _P32), ("fstr", C.POINTER(C.c_char_p)),
+                ("bp_n", (C.c_uint64 * 2) * M_MAX_FIELDS), ("bp_doc", (_P32 * 2) * M_MAX_FIELDS),
+                ("np_n", C.c_uint64 * M_MAX_FIELDS), ("np_val", C.POINTER(C.c_double) * M_MAX_FIELDS),
+                ("np_doc", _P32 * M_MAX_FIELDS),
+                ("has_used", C.c_int), ("used_n", C.c_uint64), ("used_doc", _P32)]
+
+
 class Mbmap(C.Structure):
     """mgpu_mbmap_t (include/marlin_gpu.h): one posting as mbmap stores it"""
     _fields_ = [("header", C.POINTER(C.c_uint8)), ("header_len", C.c_uint32),
@@ -223,6 +240,18 @@ def load():
         "mgpu_stage_name": (C.c_char_p, [ci]),
         "mgpu_shard_bytes": (C.c_uint64, [vp]),
         "mgpu_posting_op": (ci, [vp, vp, ci, cu, cu, C.POINTER(C.c_uint64), cu, C.POINTER(C.c_uint64)]),
+        "mbr_new": (vp, [ci, ci, ci, cu, cu]),
+        "mbr_free": (None, [vp]),
+        "mbr_add_posting": (ci, [vp, ci, cu, cu, C.POINTER(Mbmap)]),
+        "mbr_add_docdata": (ci, [vp, cu, vp, C.c_size_t]),
+        "mbr_add_num": (ci, [vp, ci, cd, cu]),
+        "mbr_set_used": (ci, [vp, C.POINTER(cu), C.c_uint64]),
+        "mbr_finish": (vp, [vp]),
+        "mshard_twid_posting": (C.c_uint64, [vp, cu, C.POINTER(C.POINTER(cu))]),
+        "mshard_twid_wids": (C.c_uint64, [vp, cu, C.POINTER(C.POINTER(cu))]),
+        "mshard_facet_posting": (C.c_uint64, [vp, ci, cu, C.POINTER(C.POINTER(cu))]),
+        "mshard_bool_posting": (C.c_uint64, [vp, ci, ci, C.POINTER(C.POINTER(cu))]),
+        "mshard_docdata": (C.POINTER(C.c_uint8), [vp, cu, C.POINTER(cu)]),
         "mgpu_mbmap_decode": (ci, [C.POINTER(Mbmap), C.POINTER(cu), C.c_uint64, C.POINTER(C.c_uint64)]),
         "mgpu_shard_create": (ci, [ci, C.POINTER(ShardDesc), C.POINTER(vp)]),
         "mgpu_shard_destroy": (None, [vp]),
@@ -233,7 +262,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    expect = [DocRank, FacetCount, Agg, QueryCfg, Query, SqResult, Result, Filter, Word, Term]
+    expect = [DocRank, FacetCount, Agg, QueryCfg, Query, SqResult, Result, Filter, Word, Term, ShardFull]
     for i, st in enumerate(expect):
         if lib.m_sizeof(i) != C.sizeof(st):
             raise RuntimeError("ctypes mirror of %s is %d bytes, library says %d"

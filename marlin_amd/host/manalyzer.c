@@ -16,7 +16,7 @@ static inline int is_token_char(unsigned char c) {
 
 static void analyze(const char *str, m_word_cb cb, void *data, int for_indexing) {
     size_t n = strlen(str);
-    chr_t token[128];
+    m_chr_t token[128];
     int len = 0, is_abbrev = 0, is_hyphen = 0, position = 0, hs = 0;
     for (size_t p = 0; p < n; p++) {
         unsigned char c = (unsigned char)str[p];

@@ -27,7 +27,7 @@ extern "C" {
 #define M_MAX_RULES       10     /* R_MAX + 1, query.h:61 */
 #define M_MAX_AGGS        16
 
-typedef uint32_t chr_t;          /* utf8proc code point, word.h */
+typedef uint32_t m_chr_t;          /* utf8proc code point, word.h */
 
 /* docrank.h:5-15 -- identical field order and sizes (24 bytes). */
 typedef struct m_docrank {
@@ -71,7 +71,7 @@ typedef enum { MTYPO_OK, MTYPO_NONE } m_typos_type;
 
 typedef struct m_word {
     int   length;
-    chr_t chars[M_MAX_WORD_LEN + 1];
+    m_chr_t chars[M_MAX_WORD_LEN + 1];
 } m_word_t;
 
 /* dtrie.h:84-88 */

@@ -60,7 +60,7 @@ void m_u32map_set(m_u32map_t *m, uint32_t key, int32_t val) {
 
 struct mdict {
     /* node arrays; node 0 is the root */
-    chr_t    *ch;
+    m_chr_t    *ch;
     uint32_t *first_child;
     uint32_t *next_sib;
     uint32_t *wid;
@@ -72,7 +72,7 @@ struct mdict {
 mdict_t *mdict_new(void) {
     mdict_t *d = calloc(1, sizeof(*d));
     d->cap_nodes = 1024;
-    d->ch = calloc(d->cap_nodes, sizeof(chr_t));
+    d->ch = calloc(d->cap_nodes, sizeof(m_chr_t));
     d->first_child = calloc(d->cap_nodes, sizeof(uint32_t));
     d->next_sib = calloc(d->cap_nodes, sizeof(uint32_t));
     d->wid = calloc(d->cap_nodes, sizeof(uint32_t));
@@ -90,17 +90,17 @@ void mdict_free(mdict_t *d) {
 uint32_t mdict_word_count(const mdict_t *d) { return d->word_count; }
 uint32_t mdict_tword_count(const mdict_t *d) { return d->tword_count; }
 
-static inline uint32_t get_child(const mdict_t *d, uint32_t n, chr_t c) {
+static inline uint32_t get_child(const mdict_t *d, uint32_t n, m_chr_t c) {
     for (uint32_t k = d->first_child[n]; k; k = d->next_sib[k]) {
         if (d->ch[k] == c) return k;
     }
     return 0;
 }
 
-static uint32_t add_child(mdict_t *d, uint32_t parent, chr_t c) {
+static uint32_t add_child(mdict_t *d, uint32_t parent, m_chr_t c) {
     if (d->num_nodes == d->cap_nodes) {
         uint32_t nc = d->cap_nodes * 2;
-        d->ch = realloc(d->ch, nc * sizeof(chr_t));
+        d->ch = realloc(d->ch, nc * sizeof(m_chr_t));
         d->first_child = realloc(d->first_child, nc * sizeof(uint32_t));
         d->next_sib = realloc(d->next_sib, nc * sizeof(uint32_t));
         d->wid = realloc(d->wid, nc * sizeof(uint32_t));
@@ -118,7 +118,7 @@ static uint32_t add_child(mdict_t *d, uint32_t parent, chr_t c) {
 }
 
 /* add_path_nodes + dtrie_insert (dtrie.c:351-377, 452-484) */
-uint32_t mdict_insert(mdict_t *d, const chr_t *str, int slen, uint32_t *twids) {
+uint32_t mdict_insert(mdict_t *d, const m_chr_t *str, int slen, uint32_t *twids) {
     uint32_t cur = 0;
     for (int i = 0; i < slen; i++) {
         uint32_t next = get_child(d, cur, str[i]);
@@ -134,7 +134,7 @@ uint32_t mdict_insert(mdict_t *d, const chr_t *str, int slen, uint32_t *twids) {
 }
 
 /* word_exists_under_root (dtrie.c:406-421) */
-uint32_t mdict_exists(const mdict_t *d, const chr_t *str, int slen, uint32_t *twids) {
+uint32_t mdict_exists(const mdict_t *d, const m_chr_t *str, int slen, uint32_t *twids) {
     uint32_t cur = 0;
     for (int i = 0; i < slen; i++) {
         uint32_t next = get_child(d, cur, str[i]);
@@ -146,7 +146,7 @@ uint32_t mdict_exists(const mdict_t *d, const chr_t *str, int slen, uint32_t *tw
 }
 
 /* lookup_word_node (dtrie.c:392-404); returns node index or UINT32_MAX */
-static uint32_t lookup_word_node(const mdict_t *d, const chr_t *str, int slen) {
+static uint32_t lookup_word_node(const mdict_t *d, const m_chr_t *str, int slen) {
     uint32_t cur = 0;
     for (int i = 0; i < slen; i++) {
         uint32_t next = get_child(d, cur, str[i]);
@@ -204,10 +204,10 @@ struct lev_data {
 /* node_lev (dtrie.c:710-760): banded Damerau-Levenshtein row per trie node.
  * rows live in one buffer, row r at rows + r*size. */
 static void node_lev(struct lev_data *ld, uint32_t n, int *prev_row, int *pprev_row,
-                     chr_t c, chr_t pc, int depth) {
+                     m_chr_t c, m_chr_t pc, int depth) {
     const int size = ld->word->length + 1;
     int *cur = prev_row + size;
-    const chr_t *str = ld->word->chars;
+    const m_chr_t *str = ld->word->chars;
 
     cur[0] = prev_row[0] + 1;
     for (int i = 1; i < size; i++) cur[i] = LEV_INF;

@@ -44,9 +44,9 @@ uint32_t mdict_word_count(const mdict_t *d);
 uint32_t mdict_tword_count(const mdict_t *d);
 
 /* dtrie_insert (dtrie.c:452): returns the wid, fills twids[0..min(len,3)) */
-uint32_t mdict_insert(mdict_t *d, const chr_t *str, int slen, uint32_t *twids);
+uint32_t mdict_insert(mdict_t *d, const m_chr_t *str, int slen, uint32_t *twids);
 /* dtrie_exists (dtrie.c:432) */
-uint32_t mdict_exists(const mdict_t *d, const chr_t *str, int slen, uint32_t *twids);
+uint32_t mdict_exists(const mdict_t *d, const m_chr_t *str, int slen, uint32_t *twids);
 /* dtrie_lookup_exact (dtrie.c:793) */
 uint32_t mdict_lookup_exact(const mdict_t *d, const m_word_t *w);
 /* dtrie_lookup_term (dtrie.c:805); caller owns *tr and must m_termresult_free it */

@@ -17,7 +17,7 @@ int mmirror_create(const mshard_t *s, int device, mmirror_t **out) {
     m->bbase = pid; pid += 2u * (uint32_t)s->num_bools;
     m->num_postings = pid;
 
-    uint64_t total = s->max_docid;
+    uint64_t total = s->has_used ? s->used_n : s->max_docid;
     total += s->wp_off[m->W + 1] + s->tp_off[m->T + 1];
     for (int f = 0; f < s->num_facets; f++) total += s->fp_off[f][s->nfid[f]];
     for (int i = 0; i < s->num_bools; i++) total += s->bp_n[i][0] + s->bp_n[i][1];
@@ -26,7 +26,8 @@ int mmirror_create(const mshard_t *s, int device, mmirror_t **out) {
     uint64_t at = 0;
     uint32_t p = 0;
     off[p++] = 0;                                           /* pid 0: every used docid (shard.c:51-53) */
-    for (uint32_t d = 1; d <= s->max_docid; d++) doc[at++] = d;
+    if (s->has_used) { memcpy(doc, s->used_doc, s->used_n * sizeof(uint32_t)); at = s->used_n; }
+    else for (uint32_t d = 1; d <= s->max_docid; d++) doc[at++] = d;
     for (uint32_t w = 1; w <= m->W; w++) {
         off[p++] = at;
         uint64_t n = s->wp_off[w + 1] - s->wp_off[w];
@@ -212,17 +213,33 @@ static int lower_filter(const mmirror_t *m, const m_filter_t *f, mplan_t *pl) {
 }
 
 int mplan_build(const mmirror_t *m, const m_query_t *q, int capture, mplan_t *pl) {
+    if (q->num_terms > MGPU_MAX_TERMS || q->num_words > MGPU_MAX_WORDS) { memset(pl, 0, sizeof(*pl)); return MGPU_E_LIMIT; }
+    const mshard_t *s = m->s;
+    /* lookup_terms (squery.c:144-167): the trie walk stays on the host */
+    m_termresult_t tr[M_MAX_QTERMS];
+    uint32_t exact_wid[M_MAX_QWORDS];
+    for (int t = 0; t < q->num_terms; t++) mdict_lookup_term(s->dict, &q->terms[t], &tr[t]);
+    for (int i = 0; i < q->num_words; i++) exact_wid[i] = mdict_lookup_exact(s->dict, &q->words[i]);
+    int rc = mplan_from_terms(m, q, tr, exact_wid, capture, pl);
+    for (int t = 0; t < q->num_terms; t++) m_termresult_free(&tr[t]);
+    return rc;
+}
+
+/* Everything of the plan after the trie walk.  tr[t] = dtrie_lookup_term's result for term t (its wordids map
+ * is extended here with the words under a twid, as set_wids_under_twid does, squery.c:62-70); exact_wid[i] =
+ * dtrie_lookup_exact's result for query word i (0 = none).  q->terms / q->words themselves are not read, so a
+ * caller whose dictionary is not an mdict (the reference's dtrie: shim/squery_gpu.c) can use it as is. */
+int mplan_from_terms(const mmirror_t *m, const m_query_t *q, m_termresult_t *tr, const uint32_t *exact_in,
+                     int capture, mplan_t *pl) {
     memset(pl, 0, sizeof(*pl));
     const mshard_t *s = m->s;
     mgpu_plan_t *p = &pl->p;
     p->num_terms = q->num_terms; p->num_words = q->num_words;
     if (q->num_terms > MGPU_MAX_TERMS || q->num_words > MGPU_MAX_WORDS) return MGPU_E_LIMIT;
 
-    m_termresult_t tr[M_MAX_QTERMS];
     m_u32map_t all; m_u32map_init(&all);
-    /* lookup_terms + process_termresult (squery.c:72-118, 144-167) */
+    /* process_termresult (squery.c:72-118) */
     for (int t = 0; t < q->num_terms; t++) {
-        mdict_lookup_term(s->dict, &q->terms[t], &tr[t]);
         const uint32_t *docs;
         if (tr[t].twid == 0 && tr[t].wordids.n == 0) { p->term_npost[t] = 0; continue; }
         if (tr[t].twid) {
@@ -254,7 +271,7 @@ int mplan_build(const mmirror_t *m, const m_query_t *q, int capture, mplan_t *pl
     uint32_t exact_wid[M_MAX_QWORDS];
     for (int i = 0; i < q->num_words; i++) {
         const uint32_t *docs;
-        uint32_t wid = mdict_lookup_exact(s->dict, &q->words[i]);
+        uint32_t wid = exact_in[i];
         exact_wid[i] = 0;
         if (wid && mshard_wid_posting(s, wid, &docs)) { exact_wid[i] = wid; p->exact_present |= (uint16_t)(1u << i); }
     }
@@ -282,7 +299,6 @@ int mplan_build(const mmirror_t *m, const m_query_t *q, int capture, mplan_t *pl
         }
         p->num_wids = nw; p->wids = pl->wids;
     }
-    for (int t = 0; t < q->num_terms; t++) m_termresult_free(&tr[t]);
     m_u32map_free(&all);
 
     /* filter */
@@ -388,6 +404,51 @@ int msq_submit_prepared(mgpu_ctx_t *ctx, const msq_prepared_t *pp) {
     return mgpu_execute_begin(ctx, pp->gs, pp->gp, pp->n);
 }
 
+/* mgpu_sqout_t -> what execute_squery leaves in struct squery_result (squery.h:34-46); takes over g's arrays */
+static int sqout_to_result(const m_query_t *q, int sidx, int num_facets, mgpu_sqout_t *g, m_sqresult_t *o) {
+    memset(o, 0, sizeof(*o));
+    if (g->status) return g->status;
+    /* perform_ranking would have taken the sampled fast-rank path (docrank.c:571): not built yet */
+    if (!q->cfg.full_scan && g->num_hits > q->cfg.full_scan_threshold && q->cfg.rank_by >= 0) return MGPU_E_UNSUPPORTED;
+    o->num_hits = g->num_hits;
+    o->rank_count = g->rank_count;
+    o->ranks = (m_docrank_t *)g->ranks; g->ranks = NULL;        /* identical 24-byte layout */
+    for (int j = 0; j < o->rank_count; j++) o->ranks[j].shard_id = 0;
+    o->num_facets = num_facets;
+    for (int f = 0; f < o->num_facets; f++) {
+        if (!q->cfg.facet_enabled[f]) continue;
+        int rcnt = g->rcount[f];
+        o->rcount[f] = rcnt;
+        o->fc[f] = calloc((size_t)(rcnt ? rcnt : 1), sizeof(m_facet_count_t));
+        for (int x = 0; x < rcnt; x++) {
+            o->fc[f][x].facet_id = g->fc[f][x].facet_id; o->fc[f][x].count = g->fc[f][x].count;
+            o->fc[f][x].shard_id = (uint8_t)sidx;
+        }
+    }
+    o->num_aggs = q->num_aggs;
+    for (int a = 0; a < q->num_aggs; a++) {
+        m_agg_t *ag = &o->aggs[a];
+        *ag = q->aggs[a]; ag->card_ids = NULL; ag->card_n = 0;
+        const mgpu_agg_out_t *ga = &g->aggs[a];
+        switch (ag->type) {
+            case MA_MAX: if (ga->max > ag->value) ag->value = ga->max; break;
+            case MA_MIN: if (ga->min < ag->value) ag->value = ga->min; break;
+            case MA_AVG: ag->sum += ga->sum; ag->count += (int)ga->count; break;
+            case MA_STATS:
+                ag->sum += ga->sum; ag->count += (int)ga->count;
+                if (ga->min < ag->min) ag->min = ga->min;
+                if (ga->max > ag->max) ag->max = ga->max;
+                break;
+            case MA_CARDINALITY: ag->card_ids = ga->card_ids; ag->card_n = ga->card_n; g->aggs[a].card_ids = NULL; break;
+            default: break;
+        }
+    }
+    o->fast_rank = false;
+    o->dbg_docid_map = g->dbg_docid_map; o->dbg_words = g->dbg_words; g->dbg_docid_map = NULL;
+    o->dbg_all_ranks = (m_docrank_t *)g->dbg_all_ranks; g->dbg_all_ranks = NULL;
+    return 0;
+}
+
 int msq_collect_prepared(mgpu_ctx_t *ctx, const msq_prepared_t *pp, m_sqresult_t *outs) {
     int n = pp->n, num_shards = pp->num_shards;
     mmirror_t *const *mirrors = pp->mirrors;
@@ -395,54 +456,27 @@ int msq_collect_prepared(mgpu_ctx_t *ctx, const msq_prepared_t *pp, m_sqresult_t
     mgpu_sqout_t *go = calloc((size_t)(n ? n : 1), sizeof(mgpu_sqout_t));
     int rc = mgpu_execute_end(ctx, go);
     for (int i = 0; i < n; i++) {
-        const m_query_t *q = queries[i / num_shards];
         int sidx = i % num_shards;
-        m_sqresult_t *o = &outs[i];
-        memset(o, 0, sizeof(*o));
-        if (rc) continue;
-        mgpu_sqout_t *g = &go[i];
-        if (g->status) { rc = g->status; continue; }
-        /* perform_ranking would have taken the sampled fast-rank path (docrank.c:571): not built yet */
-        if (!q->cfg.full_scan && g->num_hits > q->cfg.full_scan_threshold && q->cfg.rank_by >= 0) { rc = MGPU_E_UNSUPPORTED; continue; }
-        o->num_hits = g->num_hits;
-        o->rank_count = g->rank_count;
-        o->ranks = (m_docrank_t *)g->ranks; g->ranks = NULL;        /* identical 24-byte layout */
-        for (int j = 0; j < o->rank_count; j++) o->ranks[j].shard_id = 0;
-        o->num_facets = mirrors[sidx]->s->num_facets;
-        for (int f = 0; f < o->num_facets; f++) {
-            if (!q->cfg.facet_enabled[f]) continue;
-            int rcnt = g->rcount[f];
-            o->rcount[f] = rcnt;
-            o->fc[f] = calloc((size_t)(rcnt ? rcnt : 1), sizeof(m_facet_count_t));
-            for (int x = 0; x < rcnt; x++) {
-                o->fc[f][x].facet_id = g->fc[f][x].facet_id; o->fc[f][x].count = g->fc[f][x].count;
-                o->fc[f][x].shard_id = (uint8_t)sidx;
-            }
-        }
-        o->num_aggs = q->num_aggs;
-        for (int a = 0; a < q->num_aggs; a++) {
-            m_agg_t *ag = &o->aggs[a];
-            *ag = q->aggs[a]; ag->card_ids = NULL; ag->card_n = 0;
-            const mgpu_agg_out_t *ga = &g->aggs[a];
-            switch (ag->type) {
-                case MA_MAX: if (ga->max > ag->value) ag->value = ga->max; break;
-                case MA_MIN: if (ga->min < ag->value) ag->value = ga->min; break;
-                case MA_AVG: ag->sum += ga->sum; ag->count += (int)ga->count; break;
-                case MA_STATS:
-                    ag->sum += ga->sum; ag->count += (int)ga->count;
-                    if (ga->min < ag->min) ag->min = ga->min;
-                    if (ga->max > ag->max) ag->max = ga->max;
-                    break;
-                case MA_CARDINALITY: ag->card_ids = ga->card_ids; ag->card_n = ga->card_n; g->aggs[a].card_ids = NULL; break;
-                default: break;
-            }
-        }
-        o->fast_rank = false;
-        o->dbg_docid_map = g->dbg_docid_map; o->dbg_words = g->dbg_words; g->dbg_docid_map = NULL;
-        o->dbg_all_ranks = (m_docrank_t *)g->dbg_all_ranks; g->dbg_all_ranks = NULL;
+        if (rc) { memset(&outs[i], 0, sizeof(outs[i])); continue; }
+        int r1 = sqout_to_result(queries[i / num_shards], sidx, mirrors[sidx]->s->num_facets, &go[i], &outs[i]);
+        if (r1) { rc = r1; m_sqresult_free(&outs[i]); }
     }
     for (int i = 0; i < n; i++) mgpu_sqout_free(&go[i]);
     free(go);
+    return rc;
+}
+
+/* execute_squery for ONE (shard, query) whose plan the caller built (mplan_from_terms): the call a replacement
+ * squery.c makes per shard (shim/squery_gpu.c) */
+int msq_execute_plan(mgpu_ctx_t *ctx, const mmirror_t *m, const m_query_t *q, const mplan_t *pl, int shard_idx, m_sqresult_t *out) {
+    mgpu_sqout_t g;
+    mgpu_shard_t *gs = m->g;
+    memset(out, 0, sizeof(*out));
+    int rc = mgpu_execute(ctx, &gs, &pl->p, 1, &g);
+    if (rc) return rc;
+    rc = sqout_to_result(q, shard_idx, m->s->num_facets, &g, out);
+    if (rc) m_sqresult_free(out);
+    mgpu_sqout_free(&g);
     return rc;
 }
 

@@ -45,7 +45,14 @@ typedef struct mplan {
  * returns 0, or MGPU_E_UNSUPPORTED when the query would take the fast-rank path
  * (docrank.c:571) -- decided after execution from num_hits, see msq_execute. */
 int  mplan_build(const mmirror_t *m, const m_query_t *q, int capture, mplan_t *out);
+/* the same after the trie walk: tr[t] = dtrie_lookup_term's result per term (wordids get the words under a twid
+ * added), exact_wid[i] = dtrie_lookup_exact's result per query word; q->terms / q->words are not read */
+int  mplan_from_terms(const mmirror_t *m, const m_query_t *q, m_termresult_t *tr, const uint32_t *exact_wid,
+                      int capture, mplan_t *out);
 void mplan_free(mplan_t *pl);
+
+/* execute_squery for one (shard, query) pair with a plan built by the caller */
+int  msq_execute_plan(mgpu_ctx_t *ctx, const mmirror_t *m, const m_query_t *q, const mplan_t *pl, int shard_idx, m_sqresult_t *out);
 
 /* execute_squery for nq queries x num_shards shards in one GPU batch.
  * mirrors[s] for s < num_shards must live on ctx's device.

@@ -90,19 +90,19 @@ void mq_build_rank_rule(m_query_t *q) {
     memcpy(&q->rank_rule[rcount], q->cfg.rank_algo, (size_t)q->cfg.num_rules * sizeof(int));
 }
 
-static void word_cb(const chr_t *chars, int length, int position, void *data) {
+static void word_cb(const m_chr_t *chars, int length, int position, void *data) {
     (void)position;
     m_query_t *q = data;                                   /* query_string_word_cb, index.c:909-917 */
     if (q->num_words >= M_MAX_QWORDS) { q->num_words++; return; }
     m_word_t *w = &q->words[q->num_words++];
     w->length = length;
-    memcpy(w->chars, chars, sizeof(chr_t) * (size_t)length);
+    memcpy(w->chars, chars, sizeof(m_chr_t) * (size_t)length);
 }
 
 static inline void word_cat(m_word_t *dst, const m_word_t *src) {     /* wordcat, word.c */
     int n = src->length;
     if (dst->length + n > M_MAX_WORD_LEN) n = M_MAX_WORD_LEN - dst->length;
-    memcpy(dst->chars + dst->length, src->chars, sizeof(chr_t) * (size_t)n);
+    memcpy(dst->chars + dst->length, src->chars, sizeof(m_chr_t) * (size_t)n);
     dst->length += n;
 }
 
@@ -454,6 +454,7 @@ size_t m_sizeof(int which) {
         case 7: return sizeof(m_filter_t);
         case 8: return sizeof(m_word_t);
         case 9: return sizeof(m_term_t);
+        case 10: return sizeof(mshard_t);
         default: return 0;
     }
 }

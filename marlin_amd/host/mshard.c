@@ -165,7 +165,7 @@ static inline void push_widpos(mshard_builder_t *b, uint32_t wid, int priority, 
 }
 
 /* string_new_word_pos (sindex.c:658-726) */
-void msb_add_word(mshard_builder_t *b, int i_priority, const chr_t *chars, int length, int position) {
+void msb_add_word(mshard_builder_t *b, int i_priority, const m_chr_t *chars, int length, int position) {
     uint32_t tw[M_LEVLIMIT] = {0, 0, 0};
     uint32_t wid = mdict_exists(b->dict, chars, length, tw);
     if (wid == 0) {
@@ -179,7 +179,7 @@ void msb_add_word(mshard_builder_t *b, int i_priority, const chr_t *chars, int l
 }
 
 struct an_data { mshard_builder_t *b; int priority; };
-static void an_cb(const chr_t *chars, int length, int position, void *data) {
+static void an_cb(const m_chr_t *chars, int length, int position, void *data) {
     struct an_data *ad = data;
     msb_add_word(ad->b, ad->priority, chars, length, position);
 }
@@ -509,6 +509,7 @@ void mshard_free(mshard_t *s) {
     free(s->fstr_id); free(s->fstr);
     for (int i = 0; i < s->num_bools; i++) for (int v = 0; v < 2; v++) free(s->bp_doc[i][v]);
     for (int i = 0; i < s->num_numbers; i++) { free(s->np_val[i]); free(s->np_doc[i]); }
+    free(s->used_doc);
     free(s);
 }
 
@@ -660,10 +661,10 @@ mshard_t *msynth_zipf(uint64_t total_docs, uint32_t vocab, uint32_t hc_buckets, 
     mshard_builder_t *b = msb_new(1, 2, 1, 2);
     /* the vocabulary goes in first, so wid = rank + 1 in every shard */
     {
-        char w[16]; chr_t cw[16]; uint32_t tw[3];
+        char w[16]; m_chr_t cw[16]; uint32_t tw[3];
         for (uint32_t r = 0; r < vocab; r++) {
             int len = msynth_zipf_word(vocab, seed, r, w);
-            for (int i = 0; i < len; i++) cw[i] = (chr_t)w[i];
+            for (int i = 0; i < len; i++) cw[i] = (m_chr_t)w[i];
             uint32_t wid = mdict_insert(b->dict, cw, len, tw);
             ensure_wid_cap(b, wid);
             b->wid_lim[wid] = 3;

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-typedef void (*m_word_cb)(const chr_t *chars, int length, int position, void *data);
+typedef void (*m_word_cb)(const m_chr_t *chars, int length, int position, void *data);
 void m_analyze_for_indexing(const char *str, m_word_cb cb, void *data);
 void m_analyze_for_search(const char *str, m_word_cb cb, void *data);
 
@@ -69,6 +69,12 @@ typedef struct mshard {
     uint64_t  np_n[M_MAX_FIELDS];
     double   *np_val[M_MAX_FIELDS];
     uint32_t *np_doc[M_MAX_FIELDS];
+
+    /* sdata->used_bmap (shard.c:51-53) when the shard has holes (deleted documents): ascending docids in use;
+     * has_used == 0 means every docid 1..max_docid is in use */
+    int       has_used;
+    uint64_t  used_n;
+    uint32_t *used_doc;
 } mshard_t;
 
 typedef struct mshard_builder mshard_builder_t;
@@ -79,7 +85,7 @@ uint32_t msb_begin_doc(mshard_builder_t *b);
 /* index_string (sindex.c:729-736): analyze + string_new_word_pos */
 void msb_add_string(mshard_builder_t *b, int i_priority, const char *str);
 /* same effect as one analyzer callback (sindex.c:658-726) for an already tokenised word */
-void msb_add_word(mshard_builder_t *b, int i_priority, const chr_t *chars, int length, int position);
+void msb_add_word(mshard_builder_t *b, int i_priority, const m_chr_t *chars, int length, int position);
 /* F_NUMBER / F_NUMLIST element (sindex.c:827-859) */
 void msb_add_number(mshard_builder_t *b, int i_priority, double d, int is_indexed);
 /* index_string_facet / index_number_facet (sindex.c:596-649) */

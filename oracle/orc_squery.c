@@ -181,7 +181,8 @@ static uint64_t *get_matching_docids(ctx_t *c, uint64_t **maps) {
     int nt = c->num_terms;
     if (nt == 0) {                                                   /* shard_get_all_docids, shard.c:51-53 */
         uint64_t *r = bm_new(c);
-        for (uint32_t d = 1; d <= c->s->max_docid; d++) r[d >> 6] |= 1ull << (d & 63);
+        if (c->s->has_used) for (uint64_t i = 0; i < c->s->used_n; i++) { uint32_t d = c->s->used_doc[i]; r[d >> 6] |= 1ull << (d & 63); }
+        else for (uint32_t d = 1; d <= c->s->max_docid; d++) r[d >> 6] |= 1ull << (d & 63);
         return r;
     }
     if (nt == 1) return bm_dup(c, maps[0]);

@@ -1,0 +1,402 @@
+/* squery_gpu.c -- drop-in replacement for Marlin's src/main/squery.c on MI355X.
+ *
+ * Compiled against the reference's own headers (never against copies): it exports the two symbols that are the seam
+ * of the shard query path, squery.h:59-60,
+ *      void execute_squery(void *w);
+ *      void sqresult_free(struct query *q, struct squery_result *sqres);
+ * with the reference's calling convention (query.c:446 threadpool job, query.c:461 inline call, query.c:468-470
+ * free), and two set-up calls a maintainer adds where a shard is opened / after a bulk commit (sindex.c:246):
+ *      int  mgpu_shim_attach_shard(struct shard *s, int device);   -- mirror the shard's LMDB into HBM
+ *      void mgpu_shim_detach_shard(struct shard *s);
+ * What stays on the host is what north_star keeps there: the dtrie walk (dtrie_lookup_term / dtrie_lookup_exact),
+ * LMDB, filter and agg parsing.  Everything between lookup_terms and the filled squery_result runs in
+ * libmarlin_gpu.so through the host library (mplan_from_terms -> msq_execute_plan).
+ *
+ * There is NO CPU fallback in here: without an attached mirror, or on a GPU error, the shard reports zero hits and
+ * logs with M_ERR, the reference's own convention for degraded results (squery.h has no error channel).
+ *
+ * Build: `make shim` (build container only; needs /root/reference for the headers).  Link a Marlin build with this
+ * object in place of squery.o, plus -lmarlin_host -lmarlin_gpu.
+ */
+#include "squery.h"
+#include "workers.h"
+#include "debug.h"
+#include "docrank.h"
+#include "utils.h"
+#include "sindex.h"
+#include "sdata.h"
+#include "filter.h"
+#include "bmap.h"
+#include "mbmap.h"
+#include "aggs.h"
+#include "metric-aggs.h"
+#include "farmhash-c.h"
+
+#include "mplan.h"       /* marlin_amd/host: m_query_t, mplan_from_terms, msq_execute_plan, mmirror_t */
+#include "mbridge.h"     /* marlin_amd/host: mshard_t filled from a foreign store */
+
+/* ---- the layouts this file moves by pointer must be the reference's */
+_Static_assert(sizeof(struct docrank) == sizeof(m_docrank_t) && sizeof(struct docrank) == sizeof(mgpu_rank_t), "docrank layout");
+_Static_assert(offsetof(struct docrank, docid) == offsetof(m_docrank_t, docid) && offsetof(struct docrank, shard_id) == offsetof(m_docrank_t, shard_id) &&
+               offsetof(struct docrank, position) == offsetof(m_docrank_t, position) && offsetof(struct docrank, typos) == offsetof(m_docrank_t, typos), "docrank fields");
+_Static_assert(sizeof(facet_count_t) == sizeof(m_facet_count_t) && offsetof(facet_count_t, facet_id) == offsetof(m_facet_count_t, facet_id) &&
+               offsetof(facet_count_t, count) == offsetof(m_facet_count_t, count), "facet_count layout");
+_Static_assert((int)R_TYPO == MR_TYPO && (int)R_PROX == MR_PROX && (int)R_POS == MR_POS && (int)R_EXACT == MR_EXACT && (int)R_FIELD == MR_FIELD &&
+               (int)R_GEO == MR_GEO && (int)R_DONE == MR_DONE && (int)R_COMP == MR_COMP && (int)R_COMP_ASC == MR_COMP_ASC && (int)R_MAX == MR_MAX, "SORT_RULE values");
+_Static_assert((int)F_AND == MF_AND && (int)F_OR == MF_OR && (int)F_NIN == MF_NIN && (int)F_EQ == MF_EQ && (int)F_NE == MF_NE && (int)F_GT == MF_GT &&
+               (int)F_GTE == MF_GTE && (int)F_LT == MF_LT && (int)F_LTE == MF_LTE && (int)F_RANGE == MF_RANGE, "FILTER_TYPE values");
+_Static_assert((int)AGG_MAX == MA_MAX && (int)AGG_MIN == MA_MIN && (int)AGG_AVG == MA_AVG && (int)AGG_STATS == MA_STATS && (int)AGG_CARDINALITY == MA_CARDINALITY, "AGG_TYPE values");
+_Static_assert((int)PREFIX_LAST == MPREFIX_LAST && (int)PREFIX_NONE == MPREFIX_NONE && (int)TYPO_OK == MTYPO_OK, "query_cfg enums");
+_Static_assert(R_MAX + 1 <= M_MAX_RULES, "rank_rule length");
+
+/* ------------------------------------------------------------------ attached mirrors */
+#define SHIM_MAX_SHARDS 256
+#define SHIM_CTX_PER_DEVICE 16
+struct shim_entry { struct shard *shard; mshard_t *src; mmirror_t *mirror; int device; };
+static struct shim_entry g_shards[SHIM_MAX_SHARDS];
+static pthread_rwlock_t g_shards_lock = PTHREAD_RWLOCK_INITIALIZER;
+/* execution contexts (one HIP stream + workspace each), handed out per call: execute_squery runs on search_pool
+ * threads and on h2o threads alike (query.c:446,461) */
+static struct { mgpu_ctx_t *ctx[SHIM_CTX_PER_DEVICE]; int busy[SHIM_CTX_PER_DEVICE]; } g_ctx[64];
+static pthread_mutex_t g_ctx_lock = PTHREAD_MUTEX_INITIALIZER;
+static pthread_cond_t g_ctx_free = PTHREAD_COND_INITIALIZER;
+
+static mgpu_ctx_t *ctx_acquire(int device, int *slot) {
+    mgpu_ctx_t *c = NULL;
+    pthread_mutex_lock(&g_ctx_lock);
+    for (;;) {
+        for (int i = 0; i < SHIM_CTX_PER_DEVICE; i++) {
+            if (g_ctx[device].busy[i]) continue;
+            if (!g_ctx[device].ctx[i] && mgpu_ctx_create(device, 0, &g_ctx[device].ctx[i])) {
+                M_ERR("gpu squery: mgpu_ctx_create: %s", mgpu_last_error());
+                pthread_mutex_unlock(&g_ctx_lock);
+                return NULL;
+            }
+            g_ctx[device].busy[i] = 1; *slot = i; c = g_ctx[device].ctx[i];
+            break;
+        }
+        if (c) break;
+        pthread_cond_wait(&g_ctx_free, &g_ctx_lock);
+    }
+    pthread_mutex_unlock(&g_ctx_lock);
+    return c;
+}
+
+static void ctx_release(int device, int slot) {
+    pthread_mutex_lock(&g_ctx_lock);
+    g_ctx[device].busy[slot] = 0;
+    pthread_cond_signal(&g_ctx_free);
+    pthread_mutex_unlock(&g_ctx_lock);
+}
+
+/* ---- LMDB -> bridge.  A posting dbi holds, per set, the header at key IDPRIORITY(id, priority) and one value per
+ * container at key header + cid + 1 (mbmap.c:183-283): the low 16 bits of a key are 0 for headers only. */
+struct used_iter { uint32_t *v; uint64_t n, cap; };
+static void collect_used(uint32_t docid, void *data) {
+    struct used_iter *u = data;
+    if (u->n == u->cap) { u->cap = u->cap ? u->cap * 2 : 4096; u->v = realloc(u->v, u->cap * sizeof(uint32_t)); }
+    u->v[u->n++] = docid;
+}
+
+static int bridge_posting_dbi(mbridge_t *mb, MDB_txn *txn, MDB_dbi dbi, mbr_kind kind) {
+    MDB_cursor *cur;
+    if (mdb_cursor_open(txn, dbi, &cur) != 0) return MGPU_E_ARG;
+    MDB_val key, data;
+    int rc = 0;
+    const uint8_t *cont[65536 / 64];            /* a docid space of 2^26 has at most 1024 containers */
+    uint32_t cont_len[65536 / 64];
+    for (MDB_cursor_op op = MDB_FIRST; !rc && mdb_cursor_get(cur, &key, &data, op) == 0; op = MDB_NEXT) {
+        uint64_t k;
+        if (key.mv_size != sizeof(k)) continue;
+        memcpy(&k, key.mv_data, sizeof(k));
+        if (k & 0xFFFFu) continue;                                  /* a container value, fetched with its header */
+        if (data.mv_size < 2) continue;
+        uint16_t num_c; memcpy(&num_c, data.mv_data, 2);
+        if (num_c > sizeof(cont) / sizeof(cont[0]) || data.mv_size < 2u + 2u * num_c) { rc = MGPU_E_LIMIT; break; }
+        for (uint32_t i = 0; i < num_c; i++) {
+            uint16_t cid; memcpy(&cid, (const uint8_t *)data.mv_data + 2 + 2 * i, 2);
+            uint64_t ck = k + cid + 1;
+            MDB_val ckey = { sizeof(ck), &ck }, cval;
+            if (mdb_get(txn, dbi, &ckey, &cval) == 0) { cont[i] = cval.mv_data; cont_len[i] = (uint32_t)cval.mv_size; }
+            else { cont[i] = NULL; cont_len[i] = 0; }              /* mbmap_load_bmap logs and carries on (mbmap.c:276-278) */
+        }
+        mgpu_mbmap_t stored = { data.mv_data, (uint32_t)data.mv_size, cont, cont_len };
+        rc = mbr_add_posting(mb, kind, (uint32_t)(k >> 32), (uint32_t)((k >> 16) & 0xFFFFu), &stored);
+    }
+    mdb_cursor_close(cur);
+    return rc;
+}
+
+void mgpu_shim_detach_shard(struct shard *s) {
+    pthread_rwlock_wrlock(&g_shards_lock);
+    for (int i = 0; i < SHIM_MAX_SHARDS; i++) {
+        if (g_shards[i].shard != s) continue;
+        mmirror_destroy(g_shards[i].mirror);
+        mshard_free(g_shards[i].src);
+        memset(&g_shards[i], 0, sizeof(g_shards[i]));
+    }
+    pthread_rwlock_unlock(&g_shards_lock);
+}
+
+/* Mirrors one shard: every posting, docdata blob and num_dbi pair of its LMDB environment, read inside one read
+ * transaction (a consistent snapshot against the single writer, sindex.c:184-254).  Replaces an earlier mirror of the
+ * same shard.  Returns 0 or an MGPU_E_* code. */
+int mgpu_shim_attach_shard(struct shard *s, int device) {
+    struct sindex *si = s->sindex;
+    const struct mapping *map = si->map;
+    if (!map || device < 0 || device >= 64) return MGPU_E_ARG;
+    MDB_txn *txn;
+    if (mdb_txn_begin(si->env, NULL, MDB_RDONLY, &txn) != 0) return MGPU_E_ARG;
+    mbridge_t *mb = mbr_new(map->num_numbers, map->num_bools, map->num_facets,
+                            si->trie->meta->word_count, si->trie->meta->tword_count);
+    int rc = mb ? 0 : MGPU_E_LIMIT;
+    if (!rc) rc = bridge_posting_dbi(mb, txn, si->wid2bmap_dbi, MBR_WID);
+    if (!rc) rc = bridge_posting_dbi(mb, txn, si->twid2bmap_dbi, MBR_TWID);
+    if (!rc) rc = bridge_posting_dbi(mb, txn, si->twid2widbmap_dbi, MBR_TWID_WIDS);
+    if (!rc) rc = bridge_posting_dbi(mb, txn, si->facetid2bmap_dbi, MBR_FACET);
+    if (!rc) rc = bridge_posting_dbi(mb, txn, si->boolid2bmap_dbi, MBR_BOOL);
+    if (!rc) {                                                      /* docid2data: key u32 docid (sindex.c:288-291) */
+        MDB_cursor *cur; MDB_val key, data;
+        if (mdb_cursor_open(txn, si->docid2data_dbi, &cur) == 0) {
+            for (MDB_cursor_op op = MDB_FIRST; !rc && mdb_cursor_get(cur, &key, &data, op) == 0; op = MDB_NEXT) {
+                uint32_t docid;
+                if (key.mv_size != sizeof(docid)) continue;
+                memcpy(&docid, key.mv_data, sizeof(docid));
+                rc = mbr_add_docdata(mb, docid, data.mv_data, data.mv_size);
+            }
+            mdb_cursor_close(cur);
+        }
+    }
+    for (int i = 0; !rc && i < map->num_numbers; i++) {             /* num_dbi[i]: f64 keys descending, dup-sorted u32 docids */
+        MDB_cursor *cur; MDB_val key, data;
+        if (mdb_cursor_open(txn, si->num_dbi[i], &cur) != 0) continue;
+        for (MDB_cursor_op op = MDB_FIRST; !rc && mdb_cursor_get(cur, &key, &data, op) == 0; op = MDB_NEXT) {
+            double v; uint32_t docid;
+            if (key.mv_size != sizeof(v) || data.mv_size < sizeof(docid)) continue;
+            memcpy(&v, key.mv_data, sizeof(v)); memcpy(&docid, data.mv_data, sizeof(docid));
+            rc = mbr_add_num(mb, i, v, docid);
+        }
+        mdb_cursor_close(cur);
+    }
+    if (!rc) {                                                      /* shard_get_all_docids (shard.c:51-53) */
+        struct used_iter u = { NULL, 0, 0 };
+        bmap_iterate(s->sdata->used_bmap, collect_used, &u);
+        rc = mbr_set_used(mb, u.v, u.n);
+        free(u.v);
+    }
+    mdb_txn_abort(txn);
+    if (rc) { mbr_free(mb); M_ERR("gpu squery: mirroring shard %d failed (%d)", s->shard_id, rc); return rc; }
+    mshard_t *src = mbr_finish(mb);
+    mmirror_t *mirror = NULL;
+    if (!src || (rc = mmirror_create(src, device, &mirror))) {
+        M_ERR("gpu squery: mmirror_create for shard %d: %s", s->shard_id, mgpu_last_error());
+        mshard_free(src);
+        return rc ? rc : MGPU_E_LIMIT;
+    }
+    mgpu_shim_detach_shard(s);
+    pthread_rwlock_wrlock(&g_shards_lock);
+    rc = MGPU_E_LIMIT;
+    for (int i = 0; i < SHIM_MAX_SHARDS; i++) {
+        if (g_shards[i].shard) continue;
+        g_shards[i] = (struct shim_entry){ s, src, mirror, device };
+        rc = 0;
+        break;
+    }
+    pthread_rwlock_unlock(&g_shards_lock);
+    if (rc) { mmirror_destroy(mirror); mshard_free(src); }
+    return rc;
+}
+
+/* ------------------------------------------------------------------ struct query -> m_query_t */
+/* filter tree (filter.h:24-38) -> m_filter_t; leaves keep what filter_apply.c reads: type, field type, the schema's
+ * priorities, numval / numval2 / numcmp1 / numcmp2, and farmhash32(strval) for facet strings (filter_apply.c:25) */
+static m_filter_t *lower_filter_tree(const struct filter *f) {
+    m_filter_t *o = mf_new((int)f->type);
+    switch (f->field_type) {
+        case F_NUMBER: case F_NUMLIST: o->field_type = MT_NUMBER; break;
+        case F_STRING: case F_STRLIST: o->field_type = MT_STRING; break;
+        case F_BOOLEAN: o->field_type = MT_BOOLEAN; break;
+        default: o->field_type = MT_OTHER; break;
+    }
+    /* filter_apply's callbacks switch on F_NUMBER / F_STRING / F_BOOLEAN only (filter_apply.c:58-75) */
+    if (f->field_type == F_NUMLIST || f->field_type == F_STRLIST) o->field_type = MT_OTHER;
+    o->i_priority = f->s ? f->s->i_priority : -1;
+    o->f_priority = f->s ? f->s->f_priority : -1;
+    o->is_facet = f->s ? f->s->is_facet : 0;
+    if (f->strval) o->facet_id = farmhash32(f->strval, strlen(f->strval));
+    o->numval = f->numval; o->numval2 = f->numval2;
+    o->numcmp1 = (int)f->numcmp1; o->numcmp2 = (int)f->numcmp2;
+    for (size_t i = 0; i < kv_size(f->children); i++) mf_add_child(o, lower_filter_tree(kv_A(f->children, i)));
+    return o;
+}
+
+/* the query's aggs (root with metric children, aggs.c:56-90) -> flat m_agg_t list in child order */
+static int lower_aggs(const struct agg *root, m_query_t *mq) {
+    if (!root) return 0;
+    for (size_t i = 0; i < kv_size(root->children); i++) {
+        const struct agg *c = kv_A(root->children, i);
+        int field;
+        switch (c->type) {
+            case AGG_MAX: field = ((const struct agg_max *)c)->max_field; break;
+            case AGG_MIN: field = ((const struct agg_min *)c)->min_field; break;
+            case AGG_AVG: field = ((const struct agg_avg *)c)->field; break;
+            case AGG_STATS: field = ((const struct agg_stats *)c)->field; break;
+            case AGG_CARDINALITY: field = ((const struct agg_card *)c)->field; break;
+            default: return MGPU_E_UNSUPPORTED;
+        }
+        if (mq_add_agg(mq, (int)c->type, field)) return MGPU_E_LIMIT;
+    }
+    return 0;
+}
+
+static m_query_t *lower_query(const struct query *q, int num_facets) {
+    m_query_t *mq = mq_new(0);
+    mq->num_words = q->num_words;
+    mq->num_terms = (int)kv_size(q->terms);
+    mq->cfg.prefix = (int)q->cfg.prefix; mq->cfg.typos = (int)q->cfg.typos;
+    mq->cfg.hits_per_page = q->cfg.hits_per_page; mq->cfg.max_hits = q->cfg.max_hits;
+    mq->cfg.max_facet_results = q->cfg.max_facet_results;
+    mq->cfg.num_rules = q->cfg.num_rules;
+    mq->cfg.rank_by = q->cfg.rank_by; mq->cfg.rank_sort = q->cfg.rank_sort; mq->cfg.rank_asc = q->cfg.rank_asc;
+    mq->cfg.full_scan = q->cfg.full_scan; mq->cfg.full_scan_threshold = q->cfg.full_scan_threshold;
+    for (int i = 0; i <= R_MAX && i < M_MAX_RULES; i++) { mq->cfg.rank_algo[i] = (int)q->cfg.rank_algo[i]; mq->rank_rule[i] = (int)q->rank_rule[i]; }
+    for (int f = 0; f < num_facets && f < M_MAX_FIELDS; f++) mq->cfg.facet_enabled[f] = q->cfg.facet_enabled[f];
+    mq->page_num = q->page_num;
+    if (q->filter) mq->filter = lower_filter_tree(q->filter);
+    return mq;
+}
+
+/* ------------------------------------------------------------------ m_sqresult_t -> struct squery_result */
+static void copy_aggs(struct agg *root, const m_sqresult_t *r) {
+    for (size_t i = 0; i < kv_size(root->children) && (int)i < r->num_aggs; i++) {
+        struct agg *c = kv_A(root->children, i);
+        const m_agg_t *a = &r->aggs[i];
+        switch (c->type) {
+            case AGG_MAX: ((struct agg_max *)c)->value = a->value; break;
+            case AGG_MIN: ((struct agg_min *)c)->value = a->value; break;
+            case AGG_AVG: ((struct agg_avg *)c)->sum = a->sum; ((struct agg_avg *)c)->count = a->count; break;
+            case AGG_STATS: {
+                struct agg_stats *st = (struct agg_stats *)c;
+                st->sum = a->sum; st->count = a->count; st->min = a->min; st->max = a->max;
+            } break;
+            case AGG_CARDINALITY: {                 /* consume_card_agg: bmap_add per distinct facet id (metric-aggs.c:23-45) */
+                struct agg_card *ac = (struct agg_card *)c;
+                for (uint32_t x = 0; x < a->card_n; x++) bmap_add(ac->bmap, a->card_ids[x]);
+            } break;
+            default: break;
+        }
+    }
+}
+
+static void finish(struct squery *sq) {
+    if (sq->worker) worker_done(sq->worker);
+}
+
+void execute_squery(void *w) {
+    struct squery *sq = w;
+    struct query *q = sq->q;
+    const int num_terms = (int)kv_size(q->terms);
+    const int num_facets = q->in->mapping->num_facets;
+    khiter_t k;
+
+    /* what form_result and sqresult_free expect to find, whatever happens below (squery.c:20-37) */
+    struct squery_result *res = calloc(1, sizeof(*res));
+    sq->sqres = res;
+    sq->fast_rank = false;
+    res->exact_docid_map = calloc(q->num_words ? q->num_words : 1, sizeof(struct bmap *));
+    res->all_wordids = kh_init(WID2TYPOS);
+    res->fh = calloc(num_facets ? num_facets : 1, sizeof(struct facet_hash));      /* .h stays NULL: no hashtable is built */
+    res->fc = calloc(num_facets ? num_facets : 1, sizeof(struct facet_count *));
+    if (q->agg) res->agg = aggs_dup(q->agg);
+
+    /* the shard's mirror */
+    mmirror_t *mirror = NULL; int device = 0;
+    pthread_rwlock_rdlock(&g_shards_lock);
+    for (int i = 0; i < SHIM_MAX_SHARDS; i++) if (g_shards[i].shard == sq->shard) { mirror = g_shards[i].mirror; device = g_shards[i].device; break; }
+    if (!mirror) {
+        pthread_rwlock_unlock(&g_shards_lock);
+        M_ERR("gpu squery: shard %d has no mirror (mgpu_shim_attach_shard was not called)", sq->shard_idx);
+        finish(sq);
+        return;
+    }
+    if (num_terms > M_MAX_QTERMS || q->num_words > M_MAX_QWORDS) {
+        pthread_rwlock_unlock(&g_shards_lock);
+        M_ERR("gpu squery: query has %d words, limit %d", q->num_words, M_MAX_QWORDS);
+        finish(sq);
+        return;
+    }
+
+    /* unchanged host work: the trie walk (lookup_terms, squery.c:144-167) */
+    struct sindex *si = sq->shard->sindex;
+    m_termresult_t tr[M_MAX_QTERMS];
+    uint32_t exact_wid[M_MAX_QWORDS];
+    for (int t = 0; t < num_terms; t++) {
+        termresult_t *r = dtrie_lookup_term(si->trie, kv_A(q->terms, t));
+        tr[t].twid = r->twid;
+        m_u32map_init(&tr[t].wordids);
+        uint32_t wid; int dist;
+        kh_foreach(r->wordids, wid, dist, { m_u32map_set(&tr[t].wordids, wid, dist); });
+        termresult_free(r);
+    }
+    for (int i = 0; i < q->num_words; i++) exact_wid[i] = dtrie_lookup_exact(si->trie, kv_A(q->words, i));
+
+    /* struct query -> plan */
+    m_query_t *mq = lower_query(q, num_facets);
+    int rc = lower_aggs(q->agg, mq);
+    mplan_t plan;
+    memset(&plan, 0, sizeof(plan));
+    if (!rc) rc = mplan_from_terms(mirror, mq, tr, exact_wid, 0, &plan);
+    for (int t = 0; t < num_terms; t++) m_termresult_free(&tr[t]);
+
+    /* everything from get_matching_docids to the top-2N cut (squery.c:480-517), on the GPU */
+    m_sqresult_t out;
+    memset(&out, 0, sizeof(out));
+    if (!rc) {
+        int slot = 0;
+        mgpu_ctx_t *ctx = ctx_acquire(device, &slot);
+        if (!ctx) rc = MGPU_E_HIP;
+        else {
+            rc = msq_execute_plan(ctx, mirror, mq, &plan, sq->shard_idx, &out);
+            ctx_release(device, slot);
+        }
+    }
+    pthread_rwlock_unlock(&g_shards_lock);
+
+    if (rc) {
+        M_ERR("gpu squery: shard %d: error %d %s", sq->shard_idx, rc, mgpu_last_error());
+    } else {
+        /* all_wordids as process_termresult leaves it (squery.c:56-60,100-105): wid -> distance of every matching word */
+        for (uint32_t i = 0; i < plan.p.num_wids; i++)
+            if (plan.wids[i].dist != 0xFF) kh_set(WID2TYPOS, res->all_wordids, plan.wids[i].wid, plan.wids[i].dist);
+        res->num_hits = (int)out.num_hits;
+        res->rank_count = out.rank_count;
+        res->ranks = (struct docrank *)out.ranks; out.ranks = NULL;          /* identical layout, libc malloc */
+        for (int f = 0; f < num_facets && f < M_MAX_FIELDS; f++) {
+            if (!q->cfg.facet_enabled[f]) continue;
+            res->fh[f].rcount = out.rcount[f];
+            res->fc[f] = (struct facet_count *)out.fc[f]; out.fc[f] = NULL;  /* shard_id already stamped */
+        }
+        if (res->agg) copy_aggs(res->agg, &out);
+        sq->fast_rank = out.fast_rank;
+    }
+    m_sqresult_free(&out);
+    mplan_free(&plan);
+    mq_free(mq);
+    finish(sq);
+}
+
+void sqresult_free(struct query *q, struct squery_result *sqres) {
+    if (!sqres) return;
+    for (int i = 0; i < q->num_words; i++) if (sqres->exact_docid_map[i]) bmap_free(sqres->exact_docid_map[i]);
+    kh_destroy(WID2TYPOS, sqres->all_wordids);
+    free(sqres->exact_docid_map);
+    free(sqres->ranks);
+    for (int i = 0; i < q->in->mapping->num_facets; i++) {
+        if (sqres->fh[i].h) hashtable_free(sqres->fh[i].h);
+        free(sqres->fc[i]);
+    }
+    if (sqres->agg) sqres->agg->free(sqres->agg);
+    free(sqres->fc);
+    free(sqres->fh);
+    free(sqres);
+}

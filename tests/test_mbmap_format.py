@@ -57,6 +57,14 @@ def test_decode_matches_reference_iteration():
     assert any(c["header_b"] is None for c in cases)       # and the absent key
 
 
+def test_python_encoder_writes_the_reference_bytes():
+    """tests/util.py:mbmap_encode (used to feed the bridge in test_bridge.py) against the reference-made buffers"""
+    from util import mbmap_encode
+    for c in load_cases():
+        header, conts = mbmap_encode(c["docids"])
+        assert header == c["header_b"] and conts == c["conts_b"], c["name"]
+
+
 def test_malformed_values_are_refused():
     lib = ffi.load()
     c = next(x for x in load_cases() if x["name"] == "straddle")

@@ -134,3 +134,28 @@ def _same(a, b):
 def _boundary_tie(res, i):
     """the last returned key may tie with documents that were cut"""
     return i == len(res["ranks"]) - 1 and res["totalHits"] > len(res["ranks"])
+
+
+def mbmap_encode(docids):
+    """ascending unique docids -> (header bytes | None, [container bytes]) as mbmap_save writes a set (mbmap.c:183-251,
+    cont.c): array containers up to 4096 members, bitset containers above, card stored modulo 65536.  Test support;
+    tests/test_mbmap_format.py checks it byte for byte against the reference-made fixtures."""
+    import struct
+    if not docids:
+        return None, []
+    chunks = {}
+    for d in docids:
+        chunks.setdefault(d >> 16, []).append(d & 0xFFFF)
+    cids = sorted(chunks)
+    header = struct.pack("<H%dH" % len(cids), len(cids), *cids)
+    conts = []
+    for cid in cids:
+        v = chunks[cid]
+        if len(v) <= 4096:
+            conts.append(struct.pack("<HH%dH" % len(v), cid, len(v), *v))
+        else:
+            bits = bytearray(8192)
+            for x in v:
+                bits[x >> 3] |= 1 << (x & 7)
+            conts.append(struct.pack("<HH", cid, len(v) & 0xFFFF) + bytes(bits))
+    return header, conts
