@@ -554,7 +554,7 @@ struct SqHost {                          // host bookkeeping for one squery of t
 struct PendingScatter { int sq; int row; const uint32_t *src_dev; uint64_t n; };
 struct JobFix { int sq; int kind; int field; };       // kind 0 rank, 1 facet
 struct Offs {      // arena offsets per squery (zero or nonzero region relative)
-    size_t rows, hist[MGPU_MAX_FIELDS], touched[MGPU_MAX_FIELDS], ntouched[MGPU_MAX_FIELDS], facord[MGPU_MAX_FIELDS], andor, ovfcnt, docmap, blk, hits, khi, klo, ovfl, aggpart;
+    size_t rows, hist[MGPU_MAX_FIELDS], touched[MGPU_MAX_FIELDS], ntouched[MGPU_MAX_FIELDS], facord[MGPU_MAX_FIELDS], andor, ovfcnt, docmap, win, rawcnt, hitsraw, hits, khi, klo, ovfl, aggpart;
     size_t fkhi[MGPU_MAX_FIELDS], fklo[MGPU_MAX_FIELDS];
 };
 struct SelOff { size_t cand0, cand1, hist, ctl, outidx, andor; uint32_t mcap; };
@@ -727,7 +727,7 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
         q.empty = (p.has_filter && p.filter_null) ? 1 : 0;
         q.nblk = (sd.W + MG_WORDS_PER_BLOCK - 1) / MG_WORDS_PER_BLOCK;
         max_nblk = std::max(max_nblk, q.nblk);
-        h.formula_rows = 1; h.scatter_docs = 0; h.sparse_docs = 0;
+        h.formula_rows = 0; h.scatter_docs = 0; h.sparse_docs = 0;
 
         auto use_posting = [&](uint32_t pid, int *row_io, std::vector<uint32_t> *dense_list) -> int {
             // returns 0 and either appends a dense row index or schedules a scatter into *row_io
@@ -792,7 +792,7 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
             }
         }
         // Upper bound of the hit count from the match formula alone (a filter only removes hits): the
-        // per-hit arrays below are sized by it instead of by the shard.  k_scan checks the real count
+        // per-hit arrays below are sized by it instead of by the shard.  k_formula / k_order check the real count
         // against it and reports MGPU_E_LIMIT rather than writing past an array if the bound were wrong.
         {
             uint64_t hb = sd.N;
@@ -948,8 +948,12 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
             o.facord[f] = nz.take((size_t)std::max<uint32_t>(q.hit_cap, 1) * 4);
         }
         o.andor = zer.take(32); o.ovfcnt = zer.take(4);
-        o.docmap = nz.take((size_t)sd.Wp * 8); o.blk = nz.take((size_t)(q.nblk + 1) * 4);
+        // the dense docid_map exists only for the parity capture (k_formula emits the hits itself)
+        o.docmap = (p.capture & 1) ? nz.take((size_t)sd.Wp * 8) : (size_t)-1;
+        if ((q.nblk + 1) / 2 > MG_ORDER_WINDOWS) return fail(MGPU_E_LIMIT, "shard larger than 2048 formula windows (67M docids)");
+        o.win = nz.take((size_t)((q.nblk + 1) / 2) * sizeof(uint2)); o.rawcnt = zer.take(4, 4);
         const size_t hc = std::max<size_t>(q.hit_cap, 1);
+        o.hitsraw = nz.take(hc * 4);
         o.hits = nz.take(hc * 4);
         o.khi = nz.take(hc * 8); o.klo = nz.take(hc * 8);
         o.ovfl = nz.take(hc * 4);
@@ -993,7 +997,7 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
             if (std::max(so.mcap, q.hit_cap) > MG_SEL_MID_KEYS || h.fac_k[j] > MG_SEL_SOLO_K) sel_wide = true;
         }
     }
-    // batch-wide work list of hit tiles, filled by k_scan
+    // batch-wide work list of hit tiles, filled by k_order
     size_t tile_cap = 0;
     for (int i = 0; i < n; i++) tile_cap += ((size_t)sqd[i].hit_cap + MG_BLOCK - 1) / MG_BLOCK;
     if (tile_cap > 0xFFFFFFFFull) return fail(MGPU_E_LIMIT, "batch too large for the tile work list");
@@ -1058,8 +1062,8 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
         SqDev &q = sqd[i]; SqHost &h = sqh[i]; Offs &o = offs[i];
         ResHdr *hdr = (ResHdr *)(R + h.hdr_off);
         q.rows = (uint64_t *)(Z + o.rows);
-        q.docid_map = (uint64_t *)(NZ + o.docmap);
-        q.blk_cnt = (uint32_t *)(NZ + o.blk);
+        q.docid_map = o.docmap == (size_t)-1 ? nullptr : (uint64_t *)(NZ + o.docmap);
+        q.win_info = (uint2 *)(NZ + o.win); q.raw_count = (uint32_t *)(Z + o.rawcnt); q.hits_raw = (uint32_t *)(NZ + o.hitsraw);
         q.num_hits = &hdr->num_hits; q.err = &hdr->err; q.ovf_cnt = (uint32_t *)(Z + o.ovfcnt);
         q.hits = (uint32_t *)(NZ + o.hits);
         q.key_hi = (uint64_t *)(NZ + o.khi); q.key_lo = (uint64_t *)(NZ + o.klo);
@@ -1073,7 +1077,7 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
         }
         q.agg_part = (AggPart *)(NZ + o.aggpart);
         q.agg_out = hdr->agg;
-        h.docid_map_off = nz_base + o.docmap; h.hits_off = nz_base + o.hits;
+        h.docid_map_off = o.docmap == (size_t)-1 ? 0 : nz_base + o.docmap; h.hits_off = nz_base + o.hits;
         h.key_hi_off = nz_base + o.khi; h.key_lo_off = nz_base + o.klo;
     }
     for (auto &ps : pscat) {
@@ -1340,7 +1344,7 @@ static int execute_end(mgpu_ctx_t *c, mgpu_sqout_t *outs, bool *completed) {
         // algorithmic bytes (DESIGN.md byte model)
         const uint64_t B = (uint64_t)q.sh.W * 8;
         c->stage_bytes[1] += h.scatter_docs * 4;
-        c->stage_bytes[2] += h.formula_rows * B + h.sparse_docs * 4 + B + 4 * M;
+        c->stage_bytes[2] += h.formula_rows * B + h.sparse_docs * 4 + 12 * M;   // rows + lists in, raw hits out, k_order in + out
         if (h.k) c->stage_bytes[3] += M * (uint64_t)(4 + 16 + 8.0 * sh->avg_dw + (p.rank_by >= 0 ? 8 : 0) + 16);
         // facet work that rides on the rank kernel's record visit: the ordinal it leaves per hit and field (4 B
         // written), and for the directly counted fields the histogram update (8 B read-modify-write)

@@ -125,6 +125,13 @@ __device__ __forceinline__ W2 w2_load(const u64 *row, uint32_t w0, bool in0) {
     return {x.x, x.y};
 }
 
+__device__ __forceinline__ void emit_bits(u64 v, uint32_t base, uint32_t *hits, uint32_t &off) {
+    while (v) {
+        const int b = __ffsll((long long)v) - 1;
+        v &= v - 1;
+        hits[off++] = base + (uint32_t)b;
+    }
+}
 __global__ __launch_bounds__(MG_BLOCK) void k_formula(const SqDev *sqs, const uint32_t *blob) {
     const SqDev *sp = &sqs[blockIdx.y];
     const uint32_t nblk = sp->nblk;                                  // 256-word blocks of the row
@@ -138,7 +145,9 @@ __global__ __launch_bounds__(MG_BLOCK) void k_formula(const SqDev *sqs, const ui
     const uint32_t *post_doc = sp->sh.post_doc, *post_win = sp->sh.post_win;
     const uint4 *sl = (const uint4 *)(blob + sp->sl_off);
     u64 *docid_map = (u64 *)sp->docid_map;
-    uint32_t *blk_cnt = sp->blk_cnt;
+    uint2 *win_info = sp->win_info;
+    uint32_t *hits_raw = sp->hits_raw, *raw_count = sp->raw_count, *err = sp->err;
+    const uint32_t hit_cap = sp->hit_cap;
     __shared__ uint32_t s_plan[MG_PLAN_LDS];
     __shared__ uint32_t red[4];
     __shared__ __align__(16) u64 s_tile[MG_TILE_TERMS * MG_FORMULA_WORDS];
@@ -272,81 +281,75 @@ __global__ __launch_bounds__(MG_BLOCK) void k_formula(const SqDev *sqs, const ui
         }
         if (!in0) { v.a = 0; v.b = 0; }          // words past the row (the last window of a shard) hold nothing
     }
-    if (in0) *(ulonglong2 *)(docid_map + w0) = make_ulonglong2(v.a, v.b);
-    // popcounts per 256-word block: waves 0,1 cover the window's first block, waves 2,3 its second
-    const uint32_t c0 = wave_sum32((uint32_t)(__popcll(v.a) + __popcll(v.b)));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c0;
+    // (the dense docid_map is only written when somebody asked for it: parity captures)
+    if (docid_map && in0) *(ulonglong2 *)(docid_map + w0) = make_ulonglong2(v.a, v.b);
+    // bmap_iterate fused in (bmap.c:370-374, cont.c:590-610): the window's hits go straight to the raw hit list.
+    // The workgroup reserves its range with ONE atomic on the squery's counter, so the windows of a squery land in
+    // whatever order they finish; k_order puts them in window (= docid) order afterwards from {count, base}.
+    const uint32_t cnt = (uint32_t)(__popcll(v.a) + __popcll(v.b));
+    uint32_t tot;
+    uint32_t off = block_excl_scan(cnt, &tot, s_scan);
+    if (threadIdx.x == 0) {
+        uint32_t b = 0;
+        if (tot) {
+            b = atomicAdd(raw_count, tot);
+            if (b + tot > hit_cap) { atomicMax(err, (uint32_t)(-MGPU_E_LIMIT)); b = 0xFFFFFFFFu; }   // the host's bound was wrong
+        }
+        red[0] = b;
+        win_info[win] = make_uint2(tot, b);
+    }
     __syncthreads();
-    if (threadIdx.x < MG_FORMULA_WORDS / MG_WORDS_PER_BLOCK) {
-        const uint32_t b = blockIdx.x * (MG_FORMULA_WORDS / MG_WORDS_PER_BLOCK) + threadIdx.x;
-        if (b < nblk) blk_cnt[b] = red[2 * threadIdx.x] + red[2 * threadIdx.x + 1];
+    const uint32_t rbase = red[0];
+    if (cnt && rbase != 0xFFFFFFFFu) {
+        off += rbase;
+        emit_bits(v.a, w0 << 6, hits_raw, off); emit_bits(v.b, (w0 + 1) << 6, hits_raw, off);
     }
 }
 
-// exclusive scan of the per-block hit counts; one workgroup per squery
-// Also publishes the squery's hit tiles (256 hits each) on the batch-wide work list that the
-// rank and facet/agg kernels stride over: their grids never depend on a host-side guess of
-// the hit count, and a batch of uneven queries balances itself.
-__global__ __launch_bounds__(MG_BLOCK) void k_scan(const SqDev *sqs, uint2 *tile_list, uint32_t *tile_count) {
-    const SqDev &sq = sqs[blockIdx.x];
+// One workgroup per squery, after k_formula: exclusive scan of the windows' hit counts in window order, the squery's
+// hit count, and the raw hit list copied into ascending docid order (a window's hits are ascending and contiguous in
+// the raw list, at the base its workgroup was given).  Also publishes the squery's hit tiles (256 hits each) on the
+// batch-wide work list that the rank and facet/agg kernels stride over: their grids never depend on a host-side guess
+// of the hit count, and a batch of uneven queries balances itself.
+__global__ __launch_bounds__(MG_BLOCK) void k_order(const SqDev *sqs, uint2 *tile_list, uint32_t *tile_count) {
+    const SqDev *sp = &sqs[blockIdx.x];
+    const uint32_t nwin = (sp->nblk + 1) / 2;
+    const uint2 *win_info = sp->win_info;
+    const uint32_t *hits_raw = sp->hits_raw;
+    uint32_t *hits = sp->hits;
+    const uint32_t hit_cap = sp->hit_cap;
+    __shared__ uint32_t s_obase[MG_ORDER_WINDOWS + 1], s_rbase[MG_ORDER_WINDOWS];
     __shared__ uint32_t lds[8];
-    __shared__ uint32_t carry, s_base;
+    __shared__ uint32_t carry, s_tbase;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
-    for (uint32_t base = 0; base < sq.nblk; base += MG_BLOCK) {
-        uint32_t i = base + threadIdx.x;
-        uint32_t v = (i < sq.nblk) ? sq.blk_cnt[i] : 0;
+    for (uint32_t base = 0; base < nwin; base += MG_BLOCK) {
+        const uint32_t i = base + threadIdx.x;
+        const uint2 wi = (i < nwin) ? win_info[i] : make_uint2(0u, 0u);
         uint32_t tot;
-        uint32_t ex = block_excl_scan(v, &tot, lds);
-        uint32_t c = carry;
-        if (i < sq.nblk) sq.blk_cnt[i] = c + ex;
+        const uint32_t ex = block_excl_scan(wi.x, &tot, lds);
+        const uint32_t c = carry;
+        if (i < nwin) { s_obase[i] = c + ex; s_rbase[i] = wi.y; }
         __syncthreads();
         if (threadIdx.x == 0) carry = c + tot;
         __syncthreads();
     }
     uint32_t M = carry;
-    if (M > sq.hit_cap) {                // the host's bound was wrong: report, and touch no per-hit array
-        if (threadIdx.x == 0) atomicMax(sq.err, (uint32_t)(-MGPU_E_LIMIT));
+    if (M > hit_cap || *sp->err) {       // the host's bound was wrong (k_formula refused to write): report, touch no per-hit array
+        if (threadIdx.x == 0) atomicMax(sp->err, (uint32_t)(-MGPU_E_LIMIT));
         M = 0;
     }
     const uint32_t ntiles = (M + MG_BLOCK - 1) / MG_BLOCK;
-    if (threadIdx.x == 0) { *sq.num_hits = M; s_base = ntiles ? atomicAdd(tile_count, ntiles) : 0; }
+    if (threadIdx.x == 0) { s_obase[nwin] = M; *sp->num_hits = M; s_tbase = ntiles ? atomicAdd(tile_count, ntiles) : 0; }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < ntiles; i += MG_BLOCK) tile_list[s_base + i] = make_uint2(blockIdx.x, i);
-}
-
-// bmap_iterate / cont_iterate (bmap.c:370-374, cont.c:590-610): bitmap -> ascending docid list.
-// 1024 words per workgroup, 2 x 16 bytes per lane.
-__device__ __forceinline__ void emit_bits(u64 v, uint32_t base, uint32_t *hits, uint32_t &off) {
-    while (v) {
-        const int b = __ffsll((long long)v) - 1;
-        v &= v - 1;
-        hits[off++] = base + (uint32_t)b;
+    for (uint32_t i = threadIdx.x; i < ntiles; i += MG_BLOCK) tile_list[s_tbase + i] = make_uint2(blockIdx.x, i);
+    for (uint32_t x = threadIdx.x; x < M; x += MG_BLOCK) {
+        // the window holding ordered position x: the last one whose ordered base is <= x (empty windows share a base
+        // with their successor and are skipped by taking the LAST such window)
+        uint32_t lo = 0, hi = nwin;                          // invariant: s_obase[lo] <= x < s_obase[hi]
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_obase[mid] <= x) lo = mid; else hi = mid; }
+        hits[x] = hits_raw[s_rbase[lo] + (x - s_obase[lo])];
     }
-}
-__global__ __launch_bounds__(MG_BLOCK) void k_compact(const SqDev *sqs) {
-    const SqDev *sp = &sqs[blockIdx.y];
-    const uint32_t nblk = sp->nblk;
-    const uint32_t b0 = blockIdx.x * (MG_COMPACT_WORDS / MG_WORDS_PER_BLOCK);
-    if (b0 >= nblk) return;
-    const uint32_t Wp = sp->sh.Wp;
-    const u64 *docid_map = (const u64 *)sp->docid_map;
-    const uint32_t *blk_cnt = sp->blk_cnt;
-    uint32_t *hits = sp->hits;
-    if (*sp->num_hits == 0) return;      // nothing to list (or k_scan refused the squery)
-    __shared__ uint32_t lds[8];
-    const uint32_t w0 = blockIdx.x * MG_COMPACT_WORDS + 2 * threadIdx.x, w1 = w0 + 512;
-    const ulonglong2 z = make_ulonglong2(0ull, 0ull);
-    const ulonglong2 x = (w0 < Wp) ? *(const ulonglong2 *)(docid_map + w0) : z;
-    const ulonglong2 y = (w1 < Wp) ? *(const ulonglong2 *)(docid_map + w1) : z;
-    const uint32_t base0 = blk_cnt[b0];
-    const uint32_t base1 = (b0 + 2 < nblk) ? blk_cnt[b0 + 2] : 0;
-    uint32_t tot;
-    uint32_t off0 = base0 + block_excl_scan((uint32_t)(__popcll(x.x) + __popcll(x.y)), &tot, lds);
-    __syncthreads();
-    uint32_t off1 = base1 + block_excl_scan((uint32_t)(__popcll(y.x) + __popcll(y.y)), &tot, lds);
-    emit_bits(x.x, w0 << 6, hits, off0); emit_bits(x.y, (w0 + 1) << 6, hits, off0);
-    emit_bits(y.x, w1 << 6, hits, off1); emit_bits(y.y, (w1 + 1) << 6, hits, off1);
 }
 
 // ------------------------------------------------------------------ ranking
@@ -1277,7 +1280,7 @@ __device__ __forceinline__ void sel_final(const SelJob &job, const SelOut &out, 
 #define SEL_MAX_WG 64
 #define SEL_WIDE_LAUNCHES 3
 struct SelLists { uint2 *items[SEL_WIDE_LAUNCHES + 1]; uint32_t *nitems; uint32_t *fin; uint32_t *nfin; uint32_t cap_items;
-                  uint32_t *mid; uint32_t *nmid; };
+                  uint32_t *mid; uint32_t *nmid; int lanemin; };
 enum { SELMODE_HOST = 0, SELMODE_ITEMS = 2 };
 
 // The digit's bit positions folded into runs of adjacent bits inside one 32-bit word of the key
@@ -1446,6 +1449,91 @@ __device__ __forceinline__ void select_solo(const SelJob &job, const SelOut &out
     if (threadIdx.x == 0) job.ctl[SEL_DONE] = 2u;            // later launches and host rounds leave the job alone
     sel_sort_emit<SEL_SMALL_CAP, NT>(job, out, s_fhi, s_flo, s_fix, s_fcnt);
     DBG_T(tf1); DBG_ADD(DS + 3, tf0, tf1); DBG_CNT(DS + 4); if (NT == MG_BLOCK) { DBG_MAX(9, ts0, tf1, M); DBG_MAX(10, tf0, tf1, M); } else { DBG_MAX(11, ts0, tf1, M); DBG_MAX(12, tf0, tf1, M); }
+}
+
+// Small k out of a list one workgroup holds (a shard's hits for one query, top 10): no radix passes at all.
+// Lane l owns keys l, l + 256, ... (R = ceil(M / 256) of them).  The k-th smallest of the 256 per-lane MINIMA, T, is an
+// upper bound of the k-th smallest key (k lanes hold a key <= T), and a key <= T can only sit in one of the k lanes whose
+// minimum is <= T: at most k * R keys survive the cut "key <= T", and the top k are among them.  One pass for the
+// minima, a counting rank over 256 minima in LDS (no barriers inside), one pass for the survivors, then the small sort.
+// The order is (hi, lo, index) as everywhere in this file, so ties resolve to the lowest docid / facet id.
+// Requires k <= 256 < M and k * R <= SEL_SMALL_CAP (checked by the caller).
+__device__ __forceinline__ bool key_lt(u64 ah, u64 al, uint32_t ai, u64 bh, u64 bl, uint32_t bi) {
+    return ah < bh || (ah == bh && (al < bl || (al == bl && ai < bi)));
+}
+__device__ __forceinline__ void select_lanemin(const SelJob &job, const SelOut &out, uint32_t M,
+                                               u64 *s_mhi /* >= 256 */, u64 *s_mlo, uint32_t *s_mix, uint32_t *s_misc,
+                                               u64 *s_fhi, u64 *s_flo, uint32_t *s_fix, uint32_t *s_fcnt) {
+    constexpr int R = SEL_ITEMS;                                   // keys per lane held in registers at a time
+    constexpr uint32_t GROUP = (uint32_t)R * MG_BLOCK;
+    const uint32_t ngrp = (M + GROUP - 1) / GROUP;
+    const bool reg = ngrp == 1;
+    const bool gen = job.gen_touched != nullptr;
+    u64 rhi[R], rlo[R];
+    u64 mh = ~0ull, ml = ~0ull; uint32_t mi = 0xFFFFFFFFu;         // this lane's least key
+    for (uint32_t g = 0; g < ngrp; g++) {
+        if (gen) {
+            // facet keys derived from the touched bins: (0xFFFFFFFF - count, bin ordinal); the count is taken with an
+            // exchange that leaves zero behind (self-cleaned pool); a list beyond the registers is parked in key_hi/lo
+            uint32_t bins[R];
+#pragma unroll
+            for (int u = 0; u < R; u++) { const uint32_t i = g * GROUP + u * MG_BLOCK + threadIdx.x; bins[u] = (i < M) ? job.gen_touched[i] : 0xFFFFFFFFu; }
+#pragma unroll
+            for (int u = 0; u < R; u++) {
+                const bool v = bins[u] < MG_FAC_LOOKUP;
+                rhi[u] = v ? (u64)(0xFFFFFFFFu - atomicExch((uint32_t *)job.gen_hist + bins[u], 0u)) : 0xFFFFFFFFull;
+                rlo[u] = (u64)bins[u];
+                const uint32_t i = g * GROUP + u * MG_BLOCK + threadIdx.x;
+                if (!reg && i < M) { ((u64 *)job.key_hi)[i] = rhi[u]; ((u64 *)job.key_lo)[i] = rlo[u]; }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < R; u++) {
+                const uint32_t i = g * GROUP + u * MG_BLOCK + threadIdx.x;
+                rhi[u] = (i < M) ? job.key_hi[i] : ~0ull; rlo[u] = (i < M) ? job.key_lo[i] : ~0ull;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < R; u++) {
+            const uint32_t i = g * GROUP + u * MG_BLOCK + threadIdx.x;
+            if (i < M && key_lt(rhi[u], rlo[u], i, mh, ml, mi)) { mh = rhi[u]; ml = rlo[u]; mi = i; }
+        }
+    }
+    s_mhi[threadIdx.x] = mh; s_mlo[threadIdx.x] = ml; s_mix[threadIdx.x] = mi;
+    if (threadIdx.x == 0) { s_fcnt[0] = 0; s_fcnt[1] = 0; }
+    if (gen && !reg) __threadfence();
+    __syncthreads();
+    // rank of this lane's minimum among the 256 minima (all distinct: the index is part of the key)
+    uint32_t rank = 0;
+    for (int j = 0; j < MG_BLOCK; j += 4) {
+#pragma unroll
+        for (int x = 0; x < 4; x++) rank += key_lt(s_mhi[j + x], s_mlo[j + x], s_mix[j + x], mh, ml, mi) ? 1u : 0u;
+    }
+    if (rank == job.k - 1) s_misc[0] = threadIdx.x;                 // M > 256: every lane has a key, exactly one has this rank
+    __syncthreads();
+    const uint32_t tl = s_misc[0];
+    const u64 th = s_mhi[tl], tlo = s_mlo[tl]; const uint32_t ti = s_mix[tl];
+    // survivors: keys <= T, only in lanes whose minimum is <= T
+    const bool mine = rank < job.k;
+    for (uint32_t g = 0; g < ngrp; g++) {
+        if (!reg) {
+#pragma unroll
+            for (int u = 0; u < R; u++) {
+                const uint32_t i = g * GROUP + u * MG_BLOCK + threadIdx.x;
+                const bool v = mine && i < M;
+                rhi[u] = v ? job.key_hi[i] : ~0ull; rlo[u] = v ? job.key_lo[i] : ~0ull;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < R; u++) {
+            const uint32_t i = g * GROUP + u * MG_BLOCK + threadIdx.x;
+            const bool take = mine && i < M && !key_lt(th, tlo, ti, rhi[u], rlo[u], i);
+            const uint32_t p = wave_slot(take, &s_fcnt[0]);
+            if (take && p < SEL_SMALL_CAP) { s_fhi[p] = rhi[u]; s_flo[p] = rlo[u]; s_fix[p] = i; }
+        }
+    }
+    if (threadIdx.x == 0) job.ctl[SEL_DONE] = 2u;                   // later launches and host rounds leave the job alone
+    sel_sort_emit<SEL_SMALL_CAP>(job, out, s_fhi, s_flo, s_fix, s_fcnt);
 }
 
 // mode HOST : host-driven continuation, grid (gx, njobs): workgroup count from gridDim.x, vb = blockIdx.x
@@ -1684,7 +1772,7 @@ __global__ __launch_bounds__(MG_BLOCK) void k_select_first(const SelJob *jobs, c
     const uint32_t M = *job.m_ptr;
     __shared__ u64 s_fhi[SEL_SMALL_CAP], s_flo[SEL_SMALL_CAP];
     __shared__ uint32_t s_fix[SEL_SMALL_CAP], s_fcnt[2];
-    __shared__ uint32_t hist[MG_SEL_BINS];
+    __shared__ __align__(16) uint32_t hist[MG_SEL_BINS];
     __shared__ uint32_t s_scan[8], s_pcur[MG_SEL_DIGIT], s_runs[MG_SEL_DIGIT], s_misc[8];
     __shared__ u64 s_red[4 * MG_BLOCK / 64];
     DbgScope dbg_scope(13); dbg_scope.tag = M;
@@ -1718,6 +1806,11 @@ __global__ __launch_bounds__(MG_BLOCK) void k_select_first(const SelJob *jobs, c
             job.ctl[SEL_NIN] = M; job.ctl[SEL_KREM] = job.k; job.ctl[SEL_NFIN] = M; job.ctl[SEL_DONE] = 1u;
             L.fin[atomicAdd(L.nfin, 1u)] = ji;
         }
+        return;
+    }
+    if (M <= SEL_SOLO_CHUNKS * SEL_CHUNK && job.k <= MG_SEL_SOLO_K && job.k * ((M + MG_BLOCK - 1) / MG_BLOCK) <= SEL_SMALL_CAP && L.lanemin) {
+        // (hist doubles as the minima's LDS: 3 x 256 words of key + 256 of index fit its 2048 words)
+        select_lanemin(job, out, M, (u64 *)hist, (u64 *)hist + MG_BLOCK, hist + 4 * MG_BLOCK, s_misc, s_fhi, s_flo, s_fix, s_fcnt);
         return;
     }
     if (M <= SEL_SOLO_CHUNKS * SEL_CHUNK && job.k <= MG_SEL_SOLO_K) {
@@ -1910,8 +2003,7 @@ static uint32_t worklist_grid(uint32_t tile_cap) {
 void mgk_formula(hipStream_t st, const SqDev *sqs, const uint32_t *blob, uint32_t max_nblk, uint32_t nsq,
                  uint2 *tile_list, uint32_t *tile_count) {
     hipLaunchKernelGGL(k_formula, dim3((max_nblk + 1) / 2, nsq), dim3(MG_BLOCK), 0, st, sqs, blob);
-    hipLaunchKernelGGL(k_scan, dim3(nsq), dim3(MG_BLOCK), 0, st, sqs, tile_list, tile_count);
-    hipLaunchKernelGGL(k_compact, dim3((max_nblk + 3) / 4, nsq), dim3(MG_BLOCK), 0, st, sqs);
+    hipLaunchKernelGGL(k_order, dim3(nsq), dim3(MG_BLOCK), 0, st, sqs, tile_list, tile_count);
 }
 void mgk_rank(hipStream_t st, const SqDev *sqs, const uint32_t *blob, uint32_t max_n, uint32_t nsq,
               uint32_t max_tab_slots, const uint2 *tile_list, const uint32_t *tile_count, uint32_t tile_cap,
@@ -1957,6 +2049,8 @@ void mgk_select(hipStream_t st, const SelJob *jobs, const void *outs, uint32_t n
     for (int i = 0; i <= SEL_WIDE_LAUNCHES; i++) L.items[i] = (uint2 *)items_mem + (size_t)i * cap_items;
     L.nitems = counters; L.nfin = counters ? counters + 4 : nullptr; L.fin = fin_list; L.cap_items = cap_items;
     L.nmid = counters ? counters + 5 : nullptr; L.mid = fin_list ? fin_list + njobs + 1 : nullptr;
+    static const int lanemin = getenv("MGPU_NO_LANEMIN") ? 0 : 1;        // diagnostic switch: the radix select_solo instead
+    L.lanemin = lanemin;
     uint32_t gx = (max_m + SEL_CHUNK - 1) / SEL_CHUNK;
     if (!finals) {
         // first go: exactly one workgroup per job, no idle ones ...

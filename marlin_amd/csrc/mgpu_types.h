@@ -6,7 +6,7 @@
 #define MG_BLOCK        256          // threads per workgroup (4 waves of 64)
 #define MG_WORDS_PER_BLOCK 256       // u64 bitmap words per hit-count block (blk_cnt granularity)
 #define MG_FORMULA_WORDS 512         // u64 bitmap words (= 32768 docids, one "window") owned by a formula workgroup
-#define MG_COMPACT_WORDS 1024        // u64 bitmap words turned into docids by a compact workgroup
+#define MG_ORDER_WINDOWS 2048        // formula windows per squery that k_order handles (= 67M docids per shard)
 #define MG_SHORT_POSTING 32          // sparse postings up to this length carry no window index: every window scans them whole
 #define MG_MAX_STACK    8            // filter program stack depth
 #define MG_MCAP         8            // matched docwords kept per document in LDS before the overflow path
@@ -108,8 +108,10 @@ struct SqDev {
     int32_t  num_fops;
     uint32_t fops_off;               // into blob: 4 u32 per op {op, a, _, _}; operand a: dense row (>=0) or ~scratch row
     // ---- outputs of formula/compact ----
-    uint64_t *docid_map;             // [Wp]
-    uint32_t *blk_cnt;               // [nblk + 1] counts, then exclusive offsets
+    uint64_t *docid_map;             // [Wp], or NULL: only written for the parity captures
+    uint2    *win_info;              // [ceil(nblk / 2)] per formula window: {hits, base of its range in hits_raw}
+    uint32_t *hits_raw;              // [hit_cap] hits grouped by window, windows in completion order
+    uint32_t *raw_count;             // device word, zeroed per query: hits_raw entries handed out
     uint32_t nblk;
     uint32_t *num_hits;              // device word
     uint32_t *hits;                  // [hit_cap] ascending docids

@@ -13,7 +13,7 @@ import subprocess
 import pytest
 
 from marlin_amd import GpuEngine, Index, ffi
-from util import ROOT, datagen_index, mbmap_encode
+from util import ROOT, _same, datagen_index, mbmap_encode
 
 SHIM_OBJ = os.path.join(ROOT, "shim", "_build", "squery_gpu.o")
 HAVE_REF = os.path.isdir("/root/reference/src/main")
@@ -137,7 +137,7 @@ def test_bridged_shard_answers_like_the_original_on_the_gpu():
         qs = [{"q": "aaaaaab bbbbbbc", "rankBy": {"num": "desc"}},
               {"q": "aaaaaaa", "filter": {"bool": True, "num": {"$gt": 100, "$lte": 9000}}},
               {"q": "", "filter": {"facet": {"$ne": "zzz"}}, "sortBy": {"id": "asc"}, "hitsPerPage": 7, "page": 3},
-              {"q": "aaaa bbbb cccc", "aggs": {"s": {"stats": {"field": "num"}}, "c": {"cardinality": {"field": "facetlist"}}}},
+              {"q": "aaaaaaa bbbbbbb ccccccc", "aggs": {"s": {"stats": {"field": "num"}}, "c": {"cardinality": {"field": "facetlist"}}}},
               {"q": "eeeeeed", "maxFacetResults": 3}, {"q": ""}]
         for q in qs:
             g1 = eng.search(ix.query(dict(q, fullScan=True)), capture=3)
@@ -147,8 +147,8 @@ def test_bridged_shard_answers_like_the_original_on_the_gpu():
                     for e in lst:
                         e.pop("key")                            # facetid2str stays in the caller's store
                 g.pop("hits")
-            assert g1 == g2, q
-            assert g1["totalHits"] > 0
+            assert _same(g1, g2), q
+            assert g1["totalHits"] > 0, q
     finally:
         eng.close(); eng2.close()
         b.dict = None
