@@ -22,7 +22,7 @@ typedef unsigned long long u64;
 extern "C" {
 void mgk_scatter(hipStream_t st, const ScatterItem *items, uint32_t nitems);
 void mgk_formula(hipStream_t st, const SqDev *sqs, const uint32_t *blob, uint32_t max_nblk, uint32_t nsq,
-                 uint2 *tile_list, uint32_t *tile_count);
+                 uint2 *tile_list, uint32_t *tile_count, uint32_t tile_cap, uint32_t *fh_list, uint32_t *fh_count, uint32_t fh_cap);
 void mgk_rank(hipStream_t st, const SqDev *sqs, const uint32_t *blob, uint32_t max_n, uint32_t nsq,
               uint32_t max_tab_slots, const uint2 *tile_list, const uint32_t *tile_count, uint32_t tile_cap,
               unsigned long long *pool, uint32_t *pool_used, uint64_t pool_cap);
@@ -37,6 +37,7 @@ void mgk_row_op(hipStream_t st, const unsigned long long *a, const unsigned long
                 uint32_t W, int op, unsigned long long *card);
 void mgk_scatter_list(hipStream_t st, const uint32_t *src, uint64_t n, unsigned long long *dst);
 void mgk_fetch(hipStream_t st, void *dst, const void *src_pinned, size_t bytes);
+void mgk_facet_hash(hipStream_t st, const SelJob *jobs, const void *outs, const uint32_t *list, const uint32_t *count, uint32_t cap);
 }
 
 // Scratch of mgpu_posting_op_noalloc (include/marlin_gpu.h): two operand rows, the result row and the cardinality
@@ -1005,6 +1006,8 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
     const size_t off_todocnt = zer.take(8 * 4, 8);            // select work-list counters
     const size_t off_tiles = nz.take(std::max<size_t>(tile_cap, 1) * sizeof(uint2));
     const size_t off_todo = nz.take(2 * (seloff.size() + 1) * 4);                         // final list, mid list
+    const size_t off_fhcnt = zer.take(2 * 4, 8);                                          // k_facet_hash job lists: counters ...
+    const size_t off_fhlist = nz.take(2 * (seloff.size() + 1) * 4);                       // ... and the two lists
     // a job never asks for more than min(64, ceil(capacity / 2048)) workgroups per wide launch
     size_t sel_items = 1;
     for (const SelOff &so : seloff) sel_items += std::min<size_t>(64, ((size_t)so.mcap + 2047) / 2048);
@@ -1105,6 +1108,8 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
     // the keys from the touched bins themselves and k_fkeys is not launched
     const bool fuse_fk = max_fac_nord <= MG_SEL_MID_KEYS && max_fac_k <= MG_SEL_SOLO_K && !getenv("MGPU_NO_FUSED_FKEYS");
     const bool use_fdirect = !getenv("MGPU_NO_DIRECT_FACETS");
+    const bool use_fhash = !getenv("MGPU_NO_HASH_FACETS");
+    uint32_t nfhash = 0;
     seljobs.resize(seloff.size()); selouts.resize(seloff.size());
     for (size_t j = 0; j < seloff.size(); j++) {
         const SelOff &so = seloff[j]; const JobFix &jf = jobfix[j];
@@ -1142,6 +1147,10 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
                 !card_on_f && q.hit_cap <= MG_SEL_MID_KEYS) {
                 q.fdirect_mask |= 1u << f;
                 sj.gen_touched = q.fac_ord[f]; sj.m_ptr = q.num_hits;
+                // ... and with few hits not even the histogram: k_facet_hash counts the ordinals in LDS
+                if (use_fhash && sj.k <= MG_FHASH_MAX_K && q.fhash_njobs < 4) {
+                    q.fhash_mask |= 1u << f; sj.fhash = 1; q.fhash_jobs[q.fhash_njobs++] = (uint32_t)j; nfhash++;
+                }
             }
         }
     }
@@ -1207,7 +1216,8 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
     mgk_scatter(st, (const ScatterItem *)(UP + up_items), (uint32_t)items.size());
     mark();
     uint2 *d_tiles = (uint2 *)(NZ + off_tiles); uint32_t *d_tilecnt = (uint32_t *)(Z + off_tilecnt);
-    mgk_formula(st, d_sq, d_blob, max_nblk, (uint32_t)n, d_tiles, d_tilecnt);
+    uint32_t *d_fhlist = (uint32_t *)(NZ + off_fhlist), *d_fhcnt = (uint32_t *)(Z + off_fhcnt);
+    mgk_formula(st, d_sq, d_blob, max_nblk, (uint32_t)n, d_tiles, d_tilecnt, (uint32_t)tile_cap, d_fhlist, d_fhcnt, nfhash);
     mark();
     tick();
     mgk_rank(st, d_sq, d_blob, max_N, (uint32_t)n, max_tab, d_tiles, d_tilecnt, (uint32_t)tile_cap, c->pool, c->pool_used, c->pool_cap);
@@ -1218,6 +1228,7 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
     mgk_fkeys(st, UP + up_fk, (uint32_t)fkjobs.size(), max_fk);
     mgk_card(st, UP + up_card, (uint32_t)cardjobs.size(), max_fk);
     mark();
+    mgk_facet_hash(st, (const SelJob *)(UP + up_sel), UP + up_selout, d_fhlist, d_fhcnt, nfhash);
     mgk_select(st, (const SelJob *)(UP + up_sel), UP + up_selout, (uint32_t)seljobs.size(), max_selm, MG_SEL_PASSES, 0,
                NZ + off_items, sel_wide ? sel_cap_items : 0u, (uint32_t *)(Z + off_todocnt), (uint32_t *)(NZ + off_todo));
     mark();

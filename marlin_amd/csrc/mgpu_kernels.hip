@@ -22,6 +22,10 @@ __device__ __forceinline__ uint32_t wave_sum32(uint32_t v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+__device__ __forceinline__ bool key_lt(u64 ah, u64 al, uint32_t ai, u64 bh, u64 bl, uint32_t bi) {
+    // (no short circuits: the operands are loaded and compared unconditionally, so loops over LDS pipeline their loads)
+    return (ah < bh) | ((ah == bh) & ((al < bl) | ((al == bl) & (ai < bi))));
+}
 // ---- optional phase clocks (mgpu_debug_phases): cycles summed per phase over the active workgroups
 __device__ int mg_dbg_on = 0;
 __device__ unsigned long long mg_dbg_acc[32];
@@ -311,14 +315,15 @@ __global__ __launch_bounds__(MG_BLOCK) void k_formula(const SqDev *sqs, const ui
 // the raw list, at the base its workgroup was given).  Also publishes the squery's hit tiles (256 hits each) on the
 // batch-wide work list that the rank and facet/agg kernels stride over: their grids never depend on a host-side guess
 // of the hit count, and a batch of uneven queries balances itself.
-__global__ __launch_bounds__(MG_BLOCK) void k_order(const SqDev *sqs, uint2 *tile_list, uint32_t *tile_count) {
+// fh_list / fh_count: the select jobs k_facet_hash takes, by size class ([0] up to MG_FHASH_SMALL_M hits: first fh_cap
+// entries, [1] up to MG_FHASH_MAX_M: the next fh_cap); a squery names its candidates in SqDev::fhash_jobs
+__global__ __launch_bounds__(MG_BLOCK) void k_order(const SqDev *sqs, uint2 *tile_list, uint32_t *tile_count,
+                                                    uint32_t *fh_list, uint32_t *fh_count, uint32_t fh_cap) {
     const SqDev *sp = &sqs[blockIdx.x];
     const uint32_t nwin = (sp->nblk + 1) / 2;
-    const uint2 *win_info = sp->win_info;
-    const uint32_t *hits_raw = sp->hits_raw;
-    uint32_t *hits = sp->hits;
+    uint2 *win_info = sp->win_info;
     const uint32_t hit_cap = sp->hit_cap;
-    __shared__ uint32_t s_obase[MG_ORDER_WINDOWS + 1], s_rbase[MG_ORDER_WINDOWS];
+    uint32_t *p_err = sp->err, *p_num_hits = sp->num_hits;
     __shared__ uint32_t lds[8];
     __shared__ uint32_t carry, s_tbase;
     if (threadIdx.x == 0) carry = 0;
@@ -329,26 +334,53 @@ __global__ __launch_bounds__(MG_BLOCK) void k_order(const SqDev *sqs, uint2 *til
         uint32_t tot;
         const uint32_t ex = block_excl_scan(wi.x, &tot, lds);
         const uint32_t c = carry;
-        if (i < nwin) { s_obase[i] = c + ex; s_rbase[i] = wi.y; }
+        if (i < nwin) win_info[i] = make_uint2(c + ex, wi.y);       // {ordered base, raw base}: what k_order_copy reads
         __syncthreads();
         if (threadIdx.x == 0) carry = c + tot;
         __syncthreads();
     }
     uint32_t M = carry;
-    if (M > hit_cap || *sp->err) {       // the host's bound was wrong (k_formula refused to write): report, touch no per-hit array
-        if (threadIdx.x == 0) atomicMax(sp->err, (uint32_t)(-MGPU_E_LIMIT));
+    if (M > hit_cap || *p_err) {         // the host's bound was wrong (k_formula refused to write): report, touch no per-hit array
+        if (threadIdx.x == 0) atomicMax(p_err, (uint32_t)(-MGPU_E_LIMIT));
         M = 0;
     }
     const uint32_t ntiles = (M + MG_BLOCK - 1) / MG_BLOCK;
-    if (threadIdx.x == 0) { s_obase[nwin] = M; *sp->num_hits = M; s_tbase = ntiles ? atomicAdd(tile_count, ntiles) : 0; }
+    if (threadIdx.x == 0) { *p_num_hits = M; s_tbase = ntiles ? atomicAdd(tile_count, ntiles) : 0; }
+    const uint32_t nfh = sp->fhash_njobs;
+    if (threadIdx.x < nfh && M <= MG_FHASH_MAX_M) {
+        const uint32_t cls = M <= MG_FHASH_SMALL_M ? 0u : 1u;
+        const uint32_t at = atomicAdd(&fh_count[cls], 1u);
+        if (at < fh_cap) fh_list[cls * fh_cap + at] = sp->fhash_jobs[threadIdx.x];
+    }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < ntiles; i += MG_BLOCK) tile_list[s_tbase + i] = make_uint2(blockIdx.x, i);
-    for (uint32_t x = threadIdx.x; x < M; x += MG_BLOCK) {
-        // the window holding ordered position x: the last one whose ordered base is <= x (empty windows share a base
-        // with their successor and are skipped by taking the LAST such window)
-        uint32_t lo = 0, hi = nwin;                          // invariant: s_obase[lo] <= x < s_obase[hi]
-        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_obase[mid] <= x) lo = mid; else hi = mid; }
-        hits[x] = hits_raw[s_rbase[lo] + (x - s_obase[lo])];
+}
+
+// the copy itself, one tile of 256 ordered positions per work item (a squery with many hits spreads over the chip)
+__global__ __launch_bounds__(MG_BLOCK) void k_order_copy(const SqDev *sqs, const uint2 *tile_list, const uint32_t *tile_count) {
+    __shared__ uint32_t s_obase[MG_ORDER_WINDOWS + 1], s_rbase[MG_ORDER_WINDOWS];
+    const uint32_t ntiles = *tile_count;
+    for (uint32_t w = blockIdx.x; w < ntiles; w += gridDim.x) {
+        const uint2 item_v = tile_list[w];
+        const uint2 item = make_uint2(__builtin_amdgcn_readfirstlane(item_v.x), __builtin_amdgcn_readfirstlane(item_v.y));
+        const SqDev *sp = &sqs[item.x];
+        const uint32_t nwin = (sp->nblk + 1) / 2;
+        const uint2 *win_info = sp->win_info;
+        const uint32_t *hits_raw = sp->hits_raw;
+        uint32_t *hits = sp->hits;
+        const uint32_t M = *sp->num_hits;
+        for (uint32_t i = threadIdx.x; i < nwin; i += MG_BLOCK) { const uint2 wi = win_info[i]; s_obase[i] = wi.x; s_rbase[i] = wi.y; }
+        if (threadIdx.x == 0) s_obase[nwin] = M;
+        __syncthreads();
+        const uint32_t x = item.y * MG_BLOCK + threadIdx.x;
+        if (x < M) {
+            // the window holding ordered position x: the LAST one whose ordered base is <= x (an empty window shares
+            // its base with its successor)
+            uint32_t lo = 0, hi = nwin;                          // invariant: s_obase[lo] <= x < s_obase[hi]
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_obase[mid] <= x) lo = mid; else hi = mid; }
+            hits[x] = hits_raw[s_rbase[lo] + (x - s_obase[lo])];
+        }
+        __syncthreads();                                         // LDS is reused by the next work item
     }
 }
 
@@ -611,7 +643,12 @@ __global__ __launch_bounds__(MG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
     const uint32_t ntiles = *tile_count;
     const uint32_t tid = threadIdx.x;
     const uint32_t grp = tid >> 4, gl = tid & 15;
-    for (uint32_t w = blockIdx.x; w < ntiles; w += gridDim.x) {
+    // a workgroup takes a run of consecutive tiles: a squery's tiles sit together on the list, so its wid table is
+    // staged into LDS once per run instead of once per tile
+    const uint32_t per = (ntiles + gridDim.x - 1) / gridDim.x;
+    const uint32_t w_end = (blockIdx.x + 1) * per < ntiles ? (blockIdx.x + 1) * per : ntiles;
+    uint32_t tab_of = 0xFFFFFFFFu;                   // squery whose table dyn_tab holds
+    for (uint32_t w = blockIdx.x * per; w < w_end; w++) {
         DBG_T(t0);
         // the work item is the same for every lane: say so, so that the descriptor is read with scalar loads
         const uint2 item_v = tile_list[w];
@@ -636,7 +673,7 @@ __global__ __launch_bounds__(MG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
         const KeyLayout kl = load_key_layout(sp);
         const double *col = sp->sh.num_col[rb >= 0 ? rb : 0];
         const int fac_here = sp->fac_in_rank;
-        const uint32_t fac_mask = sp->hist_mask, fdirect = sp->fdirect_mask;
+        const uint32_t fac_mask = sp->hist_mask, fdirect = sp->fdirect_mask, fhash = sp->fhash_mask;
         const int nfac = sp->sh.num_facets;
         if (do_rank < 0) continue;                   // no hits requested: nobody reads the keys
         const uint32_t M = *p_num_hits;
@@ -646,8 +683,10 @@ __global__ __launch_bounds__(MG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
         const uint32_t docid = valid ? p_hits[t] : 0xFFFFFFFFu;
         const bool val_in_rec = rb >= 0 && (uint32_t)rb < rec_nnum;
         if (do_rank || val_in_rec) {
-            if (do_rank && hmask < MG_LDS_HASH)
+            if (do_rank && hmask < MG_LDS_HASH && tab_of != item.x) {
                 for (uint32_t i = tid; i <= hmask; i += MG_BLOCK) dyn_tab[i] = gtab[i];
+                tab_of = item.x;
+            }
             s_doc[tid] = docid; s_cnt[tid] = 0; s_np[tid] = 0;
             __syncthreads();
             DBG_T(t1); DBG_ADD(0, t0, t1);
@@ -790,7 +829,9 @@ __global__ __launch_bounds__(MG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                         } else staged_ok = false;
                         if ((hist_mask >> f) & 1u) sp->fac_ord[f][t] = code;
                         // directly counted field: one fire-and-forget atomic, nothing waits for it
-                        if (((fdirect >> f) & 1u) && code < MG_FAC_LOOKUP) atomicAdd(&sp->hist[f][code], 1u);
+                        // (unless the select stage counts the field by hashing the ordinals: few enough hits)
+                        if (((fdirect >> f) & 1u) && code < MG_FAC_LOOKUP && !(((fhash >> f) & 1u) && M <= MG_FHASH_MAX_M))
+                            atomicAdd(&sp->hist[f][code], 1u);
                     }
                 }
                 s_np[tid] = 0;
@@ -1217,6 +1258,31 @@ __device__ __forceinline__ void sel_sort_emit(const SelJob &job, const SelOut &o
     if (threadIdx.x == 0) *job.out_n = s_cnt[1];
 }
 
+// The same result without a sort, for sets of at most CAP <= 512 keys: every key counts the keys before it (the
+// (hi, lo, idx) order is total), which IS its place in the output; no barrier in the counting.  Two keys per lane at
+// most for 256 lanes, so the loop over the set runs once or twice.
+template <int CAP, int NT = MG_BLOCK>
+__device__ __forceinline__ void sel_rank_emit(const SelJob &job, const SelOut &out, u64 *s_hi, u64 *s_lo, uint32_t *s_ix, uint32_t *s_cnt) {
+    __syncthreads();
+    const uint32_t n = s_cnt[0] < (uint32_t)CAP ? s_cnt[0] : (uint32_t)CAP;
+    for (uint32_t c = threadIdx.x; c < n; c += NT) {
+        const u64 h = s_hi[c], l = s_lo[c]; const uint32_t ix = s_ix[c];
+        if (job.skip_ones && h >= 0xFFFFFFFFull) continue;             // facet entries with a zero count (see SqDev::fdirect_mask): they sort last
+        uint32_t r = 0;
+#pragma unroll 8
+        for (uint32_t j = 0; j < n; j++) r += key_lt(s_hi[j], s_lo[j], s_ix[j], h, l, ix) ? 1u : 0u;
+        if (r < job.k) {
+            // derived facet keys carry the bin ordinal (same order as the facet id: ordinals are ranks of
+            // the sorted ids); the id itself is looked up for the k winners only
+            out.out_hi[r] = h; out.out_lo[r] = job.gen_touched ? (u64)job.gen_ord2id[l] : l;
+            out.out_pl[r] = out.payload ? out.payload[ix] : ix;
+            atomicAdd(&s_cnt[1], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *job.out_n = s_cnt[1];
+}
+
 // Final step of a selection, run by one workgroup: gather the winners the passes found and the
 // last candidate list with the last decision applied, bitonic-sort them by (hi, lo, idx) in LDS and
 // emit the first k.  s_cnt: two LDS words.
@@ -1447,7 +1513,7 @@ __device__ __forceinline__ void select_solo(const SelJob &job, const SelOut &out
     }
 #undef SOLO_LOAD
     if (threadIdx.x == 0) job.ctl[SEL_DONE] = 2u;            // later launches and host rounds leave the job alone
-    sel_sort_emit<SEL_SMALL_CAP, NT>(job, out, s_fhi, s_flo, s_fix, s_fcnt);
+    sel_rank_emit<SEL_SMALL_CAP, NT>(job, out, s_fhi, s_flo, s_fix, s_fcnt);
     DBG_T(tf1); DBG_ADD(DS + 3, tf0, tf1); DBG_CNT(DS + 4); if (NT == MG_BLOCK) { DBG_MAX(9, ts0, tf1, M); DBG_MAX(10, tf0, tf1, M); } else { DBG_MAX(11, ts0, tf1, M); DBG_MAX(12, tf0, tf1, M); }
 }
 
@@ -1458,17 +1524,39 @@ __device__ __forceinline__ void select_solo(const SelJob &job, const SelOut &out
 // minima, a counting rank over 256 minima in LDS (no barriers inside), one pass for the survivors, then the small sort.
 // The order is (hi, lo, index) as everywhere in this file, so ties resolve to the lowest docid / facet id.
 // Requires k <= 256 < M and k * R <= SEL_SMALL_CAP (checked by the caller).
-__device__ __forceinline__ bool key_lt(u64 ah, u64 al, uint32_t ai, u64 bh, u64 bl, uint32_t bi) {
-    return ah < bh || (ah == bh && (al < bl || (al == bl && ai < bi)));
+// Rank of this lane's key (h, l, i) among the NT lanes' keys when it is one of the k smallest, else some number >= k.
+// Keys must differ between lanes.  Two levels: every wave ranks its 64 keys with lane broadcasts (no LDS), the min(k, 64)
+// smallest of each wave -- the only ones that can be among the k smallest overall -- meet in LDS and are ranked against
+// each other.  b_hi / b_lo / b_ix: (NT / 64) * min(k, 64) entries each.  Contains one barrier.
+template <int NT>
+__device__ __forceinline__ uint32_t lane_rank_below_k(u64 h, u64 l, uint32_t i, uint32_t k, u64 *b_hi, u64 *b_lo, uint32_t *b_ix) {
+    const uint32_t wave = threadIdx.x >> 6;
+    uint32_t lr = 0;
+#pragma unroll
+    for (int j = 0; j < 64; j++) {
+        const u64 oh = __shfl(h, j, 64), ol = __shfl(l, j, 64);
+        const uint32_t oi = __shfl(i, j, 64);
+        lr += key_lt(oh, ol, oi, h, l, i) ? 1u : 0u;
+    }
+    const uint32_t kk = k < 64 ? k : 64;
+    if (lr < kk) { b_hi[wave * kk + lr] = h; b_lo[wave * kk + lr] = l; b_ix[wave * kk + lr] = i; }
+    __syncthreads();
+    if (lr >= kk) return k;
+    uint32_t r = 0;
+#pragma unroll 8
+    for (uint32_t x = 0; x < (NT / 64) * kk; x++) r += key_lt(b_hi[x], b_lo[x], b_ix[x], h, l, i) ? 1u : 0u;
+    return r;
 }
+
+template <int NT>
 __device__ __forceinline__ void select_lanemin(const SelJob &job, const SelOut &out, uint32_t M,
-                                               u64 *s_mhi /* >= 256 */, u64 *s_mlo, uint32_t *s_mix, uint32_t *s_misc,
-                                               u64 *s_fhi, u64 *s_flo, uint32_t *s_fix, uint32_t *s_fcnt) {
+                                               u64 *b_hi /* >= (NT / 64) * 64 */, u64 *b_lo, uint32_t *b_ix, uint32_t *s_misc /* >= 6 */,
+                                               u64 *s_fhi, u64 *s_flo, uint32_t *s_fix, uint32_t *s_fcnt, bool pregen = false) {
     constexpr int R = SEL_ITEMS;                                   // keys per lane held in registers at a time
-    constexpr uint32_t GROUP = (uint32_t)R * MG_BLOCK;
+    constexpr uint32_t GROUP = (uint32_t)R * NT;
     const uint32_t ngrp = (M + GROUP - 1) / GROUP;
     const bool reg = ngrp == 1;
-    const bool gen = job.gen_touched != nullptr;
+    const bool gen = job.gen_touched != nullptr && !pregen;        // pregen: derived facet keys already sit in key_hi / key_lo
     u64 rhi[R], rlo[R];
     u64 mh = ~0ull, ml = ~0ull; uint32_t mi = 0xFFFFFFFFu;         // this lane's least key
     for (uint32_t g = 0; g < ngrp; g++) {
@@ -1477,63 +1565,57 @@ __device__ __forceinline__ void select_lanemin(const SelJob &job, const SelOut &
             // exchange that leaves zero behind (self-cleaned pool); a list beyond the registers is parked in key_hi/lo
             uint32_t bins[R];
 #pragma unroll
-            for (int u = 0; u < R; u++) { const uint32_t i = g * GROUP + u * MG_BLOCK + threadIdx.x; bins[u] = (i < M) ? job.gen_touched[i] : 0xFFFFFFFFu; }
+            for (int u = 0; u < R; u++) { const uint32_t i = g * GROUP + u * NT + threadIdx.x; bins[u] = (i < M) ? job.gen_touched[i] : 0xFFFFFFFFu; }
 #pragma unroll
             for (int u = 0; u < R; u++) {
                 const bool v = bins[u] < MG_FAC_LOOKUP;
                 rhi[u] = v ? (u64)(0xFFFFFFFFu - atomicExch((uint32_t *)job.gen_hist + bins[u], 0u)) : 0xFFFFFFFFull;
                 rlo[u] = (u64)bins[u];
-                const uint32_t i = g * GROUP + u * MG_BLOCK + threadIdx.x;
+                const uint32_t i = g * GROUP + u * NT + threadIdx.x;
                 if (!reg && i < M) { ((u64 *)job.key_hi)[i] = rhi[u]; ((u64 *)job.key_lo)[i] = rlo[u]; }
             }
         } else {
 #pragma unroll
             for (int u = 0; u < R; u++) {
-                const uint32_t i = g * GROUP + u * MG_BLOCK + threadIdx.x;
+                const uint32_t i = g * GROUP + u * NT + threadIdx.x;
                 rhi[u] = (i < M) ? job.key_hi[i] : ~0ull; rlo[u] = (i < M) ? job.key_lo[i] : ~0ull;
             }
         }
 #pragma unroll
         for (int u = 0; u < R; u++) {
-            const uint32_t i = g * GROUP + u * MG_BLOCK + threadIdx.x;
+            const uint32_t i = g * GROUP + u * NT + threadIdx.x;
             if (i < M && key_lt(rhi[u], rlo[u], i, mh, ml, mi)) { mh = rhi[u]; ml = rlo[u]; mi = i; }
         }
     }
-    s_mhi[threadIdx.x] = mh; s_mlo[threadIdx.x] = ml; s_mix[threadIdx.x] = mi;
     if (threadIdx.x == 0) { s_fcnt[0] = 0; s_fcnt[1] = 0; }
     if (gen && !reg) __threadfence();
+    // rank of this lane's minimum among the NT minima (all distinct: M > NT, and the index is part of the key)
+    const uint32_t rank = lane_rank_below_k<NT>(mh, ml, mi, job.k, b_hi, b_lo, b_ix);
+    if (rank == job.k - 1) { s_fhi[SEL_SMALL_CAP - 1] = mh; s_flo[SEL_SMALL_CAP - 1] = ml; s_misc[0] = mi; }   // T; exactly one lane
     __syncthreads();
-    // rank of this lane's minimum among the 256 minima (all distinct: the index is part of the key)
-    uint32_t rank = 0;
-    for (int j = 0; j < MG_BLOCK; j += 4) {
-#pragma unroll
-        for (int x = 0; x < 4; x++) rank += key_lt(s_mhi[j + x], s_mlo[j + x], s_mix[j + x], mh, ml, mi) ? 1u : 0u;
-    }
-    if (rank == job.k - 1) s_misc[0] = threadIdx.x;                 // M > 256: every lane has a key, exactly one has this rank
-    __syncthreads();
-    const uint32_t tl = s_misc[0];
-    const u64 th = s_mhi[tl], tlo = s_mlo[tl]; const uint32_t ti = s_mix[tl];
+    const u64 th = s_fhi[SEL_SMALL_CAP - 1], tlo = s_flo[SEL_SMALL_CAP - 1]; const uint32_t ti = s_misc[0];
+    __syncthreads();                                                // (the slot is an ordinary output slot again from here on)
     // survivors: keys <= T, only in lanes whose minimum is <= T
     const bool mine = rank < job.k;
     for (uint32_t g = 0; g < ngrp; g++) {
         if (!reg) {
 #pragma unroll
             for (int u = 0; u < R; u++) {
-                const uint32_t i = g * GROUP + u * MG_BLOCK + threadIdx.x;
+                const uint32_t i = g * GROUP + u * NT + threadIdx.x;
                 const bool v = mine && i < M;
                 rhi[u] = v ? job.key_hi[i] : ~0ull; rlo[u] = v ? job.key_lo[i] : ~0ull;
             }
         }
 #pragma unroll
         for (int u = 0; u < R; u++) {
-            const uint32_t i = g * GROUP + u * MG_BLOCK + threadIdx.x;
+            const uint32_t i = g * GROUP + u * NT + threadIdx.x;
             const bool take = mine && i < M && !key_lt(th, tlo, ti, rhi[u], rlo[u], i);
             const uint32_t p = wave_slot(take, &s_fcnt[0]);
             if (take && p < SEL_SMALL_CAP) { s_fhi[p] = rhi[u]; s_flo[p] = rlo[u]; s_fix[p] = i; }
         }
     }
     if (threadIdx.x == 0) job.ctl[SEL_DONE] = 2u;                   // later launches and host rounds leave the job alone
-    sel_sort_emit<SEL_SMALL_CAP>(job, out, s_fhi, s_flo, s_fix, s_fcnt);
+    sel_rank_emit<SEL_SMALL_CAP, NT>(job, out, s_fhi, s_flo, s_fix, s_fcnt);
 }
 
 // mode HOST : host-driven continuation, grid (gx, njobs): workgroup count from gridDim.x, vb = blockIdx.x
@@ -1756,6 +1838,90 @@ __device__ __forceinline__ void select_job(const SelJob &job, const SelOut &sel_
     }
 }
 
+// ------------------------------------------------------------------ sparse facet field, few hits: count by hashing
+// process_facet_result + sort_facets (docrank.c:371-389, squery.c:411-437) for a field with far more values than the
+// squery has hits (100k buckets, a few thousand hits).  The hits' ordinals (fac_ord, left behind by the rank kernel)
+// are counted in an LDS hash table -- no global histogram, no atomics outside the CU -- in ONE pass: the table has at
+// least twice as many slots as the squery has hits, so linear probing always finds room.  The table's best k (count
+// desc, ordinal asc = facet id asc) are cut out with the lane-minimum bound of select_lanemin (16 slots per lane: at
+// most 16 k keys survive) and put in order by counting ranks.  Two sizes of the same kernel: 256 lanes / 4096 slots for
+// up to MG_FHASH_SMALL_M hits, 1024 lanes / 16384 slots up to MG_FHASH_MAX_M; a job runs in the one its M selects.
+#define FH_PER_LANE 16
+template <int NT>
+__global__ __launch_bounds__(NT) void k_facet_hash(const SelJob *jobs, const SelOut *outs, const uint32_t *list, const uint32_t *count, uint32_t cap) {
+    constexpr uint32_t SLOTS = (uint32_t)NT * FH_PER_LANE;
+    constexpr uint32_t CAND = MG_FHASH_MAX_K * FH_PER_LANE;
+    __shared__ uint32_t t_key[SLOTS], t_cnt[SLOTS];
+    __shared__ u64 s_bhi[(NT / 64) * MG_FHASH_MAX_K], s_blo[(NT / 64) * MG_FHASH_MAX_K];
+    __shared__ uint32_t s_bix[(NT / 64) * MG_FHASH_MAX_K];
+    __shared__ u64 s_cand[CAND];
+    __shared__ uint32_t s_n[2];
+    __shared__ u64 s_T;
+    uint32_t n = *count; if (n > cap) n = cap;
+    for (uint32_t w = blockIdx.x; w < n; w += gridDim.x) {
+        const uint32_t ji = __builtin_amdgcn_readfirstlane(list[w]);
+        const SelJob job = jobs[ji];
+        const SelOut out = outs[ji];
+        const uint32_t M = *job.m_ptr;
+        const uint32_t k = job.k;
+        const uint32_t *ords = job.gen_touched;
+        for (uint32_t i = threadIdx.x; i < SLOTS; i += NT) { t_key[i] = 0xFFFFFFFFu; t_cnt[i] = 0; }
+        if (threadIdx.x == 0) { s_n[0] = 0; s_T = 0xFFFFFFFFFFFFFFFEull; }
+        __syncthreads();
+        for (uint32_t i0 = 0; i0 < M; i0 += 4 * NT) {
+            uint32_t o[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const uint32_t i = i0 + u * NT + threadIdx.x; o[u] = (i < M) ? ords[i] : 0xFFFFFFFFu; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (o[u] >= MG_FAC_LOOKUP) continue;              // the document has no value in the field
+                uint32_t sl = hash_wid(o[u] + 1u) & (SLOTS - 1);
+                for (;; sl = (sl + 1) & (SLOTS - 1)) {            // ends: fewer distinct values than slots (M <= SLOTS / 2)
+                    const uint32_t old = atomicCAS(&t_key[sl], 0xFFFFFFFFu, o[u]);
+                    if (old == 0xFFFFFFFFu || old == o[u]) { atomicAdd(&t_cnt[sl], 1u); break; }
+                }
+            }
+        }
+        __syncthreads();
+        // this lane's slots as keys ((~count) << 32 | ordinal; empty = ~0), and their minimum
+        u64 key[FH_PER_LANE], mn = ~0ull;
+#pragma unroll
+        for (int u = 0; u < FH_PER_LANE; u++) {
+            const uint32_t sl = u * NT + threadIdx.x;
+            const uint32_t kk = t_key[sl];
+            key[u] = kk == 0xFFFFFFFFu ? ~0ull : (((u64)(0xFFFFFFFFu - t_cnt[sl])) << 32) | kk;
+            mn = key[u] < mn ? key[u] : mn;
+        }
+        // rank of the minimum among the lanes' minima (the lane number makes empty lanes distinct)
+        const uint32_t rank = lane_rank_below_k<NT>(mn, 0ull, threadIdx.x, k, s_bhi, s_blo, s_bix);
+        if (rank == k - 1 && mn != ~0ull) s_T = mn;               // the k-th smallest minimum bounds the k-th smallest key
+        __syncthreads();
+        const u64 T = s_T;
+#pragma unroll
+        for (int u = 0; u < FH_PER_LANE; u++) {
+            const bool take = rank < k && key[u] <= T;
+            const uint32_t at = wave_slot(take, &s_n[0]);
+            if (take && at < CAND) s_cand[at] = key[u];
+        }
+        __syncthreads();
+        // counting rank: a candidate with r smaller ones is the r-th of the result (every key is distinct: one per ordinal)
+        const uint32_t nc = s_n[0] < CAND ? s_n[0] : CAND;
+        for (uint32_t c = threadIdx.x; c < nc; c += NT) {
+            const u64 mine = s_cand[c];
+            uint32_t r = 0;
+#pragma unroll 8
+            for (uint32_t j = 0; j < nc; j++) r += s_cand[j] < mine ? 1u : 0u;
+            if (r < k) {
+                out.out_hi[r] = mine >> 32;
+                out.out_lo[r] = (u64)job.gen_ord2id[(uint32_t)mine];
+                out.out_pl[r] = 0;
+            }
+        }
+        if (threadIdx.x == 0) { *job.out_n = nc < k ? nc : k; job.ctl[SEL_DONE] = 2u; }
+        __syncthreads();                                          // LDS is reused by the next job
+    }
+}
+
 // host-driven continuation rounds: grid (gx, njobs)
 __global__ __launch_bounds__(MG_BLOCK) void k_select_pass(const SelJob *jobs, const SelOut *outs, int mode, SelLists L) {
     const SelJob job = jobs[blockIdx.y];
@@ -1776,6 +1942,7 @@ __global__ __launch_bounds__(MG_BLOCK) void k_select_first(const SelJob *jobs, c
     __shared__ uint32_t s_scan[8], s_pcur[MG_SEL_DIGIT], s_runs[MG_SEL_DIGIT], s_misc[8];
     __shared__ u64 s_red[4 * MG_BLOCK / 64];
     DbgScope dbg_scope(13); dbg_scope.tag = M;
+    if (job.fhash && M <= MG_FHASH_MAX_M) return;                // k_facet_hash's job
     if (M <= SEL_SMALL_CAP) {
         // short list: straight into the sort
         if (threadIdx.x == 0) { job.ctl[SEL_NIN] = M; job.ctl[SEL_KREM] = job.k; job.ctl[SEL_NFIN] = M; job.ctl[SEL_DONE] = 2u;
@@ -1797,7 +1964,7 @@ __global__ __launch_bounds__(MG_BLOCK) void k_select_first(const SelJob *jobs, c
                 s_fix[i] = i;
             }
         }
-        sel_sort_emit<SEL_SMALL_CAP>(job, out, s_fhi, s_flo, s_fix, s_fcnt);
+        sel_rank_emit<SEL_SMALL_CAP>(job, out, s_fhi, s_flo, s_fix, s_fcnt);
         return;
     }
     if (threadIdx.x == 0) *job.out_n = 0xFFFFFFFFu;          // until a final sort has run the host must see "not finished"
@@ -1810,7 +1977,7 @@ __global__ __launch_bounds__(MG_BLOCK) void k_select_first(const SelJob *jobs, c
     }
     if (M <= SEL_SOLO_CHUNKS * SEL_CHUNK && job.k <= MG_SEL_SOLO_K && job.k * ((M + MG_BLOCK - 1) / MG_BLOCK) <= SEL_SMALL_CAP && L.lanemin) {
         // (hist doubles as the minima's LDS: 3 x 256 words of key + 256 of index fit its 2048 words)
-        select_lanemin(job, out, M, (u64 *)hist, (u64 *)hist + MG_BLOCK, hist + 4 * MG_BLOCK, s_misc, s_fhi, s_flo, s_fix, s_fcnt);
+        select_lanemin<MG_BLOCK>(job, out, M, (u64 *)hist, (u64 *)hist + MG_BLOCK, hist + 4 * MG_BLOCK, s_misc, s_fhi, s_flo, s_fix, s_fcnt);
         return;
     }
     if (M <= SEL_SOLO_CHUNKS * SEL_CHUNK && job.k <= MG_SEL_SOLO_K) {
@@ -1865,15 +2032,21 @@ __global__ __launch_bounds__(SEL_MID_BLOCK) void k_select_mid(const SelJob *jobs
     __shared__ uint32_t hist[MG_SEL_BINS];
     __shared__ uint32_t s_scan[SEL_MID_BLOCK / 64], s_pcur[MG_SEL_DIGIT], s_runs[MG_SEL_DIGIT], s_misc[8];
     __shared__ u64 s_red[4 * SEL_MID_BLOCK / 64];
+    __shared__ u64 s_bhi[SEL_MID_BLOCK], s_blo[SEL_MID_BLOCK];          // lane_rank_below_k: (1024 / 64) * 64 entries
+    __shared__ uint32_t s_bix[SEL_MID_BLOCK];
     const uint32_t n = *L.nmid;
     for (uint32_t w = blockIdx.x; w < n; w += gridDim.x) {
         const uint32_t ji = L.mid[w];
         const SelJob job = jobs[ji];
         const uint32_t M = *job.m_ptr;
-        u64 mhi, mlo; uint32_t midx;
-        job_masks(job, M, mhi, mlo, midx);
         // (derived facet keys of these long lists were written out by k_fkeys_mid, many workgroups per list)
-        select_solo<SEL_MID_BLOCK>(job, outs[ji], M, mhi, mlo, midx, hist, s_scan, s_pcur, s_runs, s_misc, s_fhi, s_flo, s_fix, s_fcnt, s_red, true);
+        if (L.lanemin && job.k * ((M + SEL_MID_BLOCK - 1) / SEL_MID_BLOCK) <= SEL_SMALL_CAP) {
+            select_lanemin<SEL_MID_BLOCK>(job, outs[ji], M, s_bhi, s_blo, s_bix, s_misc, s_fhi, s_flo, s_fix, s_fcnt, true);
+        } else {
+            u64 mhi, mlo; uint32_t midx;
+            job_masks(job, M, mhi, mlo, midx);
+            select_solo<SEL_MID_BLOCK>(job, outs[ji], M, mhi, mlo, midx, hist, s_scan, s_pcur, s_runs, s_misc, s_fhi, s_flo, s_fix, s_fcnt, s_red, true);
+        }
         __syncthreads();
     }
 }
@@ -2001,9 +2174,10 @@ static uint32_t worklist_grid(uint32_t tile_cap) {
     return g ? g : 1;
 }
 void mgk_formula(hipStream_t st, const SqDev *sqs, const uint32_t *blob, uint32_t max_nblk, uint32_t nsq,
-                 uint2 *tile_list, uint32_t *tile_count) {
+                 uint2 *tile_list, uint32_t *tile_count, uint32_t tile_cap, uint32_t *fh_list, uint32_t *fh_count, uint32_t fh_cap) {
     hipLaunchKernelGGL(k_formula, dim3((max_nblk + 1) / 2, nsq), dim3(MG_BLOCK), 0, st, sqs, blob);
-    hipLaunchKernelGGL(k_order, dim3(nsq), dim3(MG_BLOCK), 0, st, sqs, tile_list, tile_count);
+    hipLaunchKernelGGL(k_order, dim3(nsq), dim3(MG_BLOCK), 0, st, sqs, tile_list, tile_count, fh_list, fh_count, fh_cap);
+    hipLaunchKernelGGL(k_order_copy, dim3(worklist_grid(tile_cap)), dim3(MG_BLOCK), 0, st, sqs, tile_list, tile_count);
 }
 void mgk_rank(hipStream_t st, const SqDev *sqs, const uint32_t *blob, uint32_t max_n, uint32_t nsq,
               uint32_t max_tab_slots, const uint2 *tile_list, const uint32_t *tile_count, uint32_t tile_cap,
@@ -2041,6 +2215,12 @@ void mgk_card(hipStream_t st, const void *jobs, uint32_t njobs, uint32_t max_n) 
 // lists: device memory for the select work lists: counters = 6 zeroed u32 words (4 item counters, the
 // final-list counter, the mid-list counter), items = (SEL_WIDE_LAUNCHES + 1) arrays of cap_items uint2,
 // fin_list = 2 * (njobs + 1) u32 (final list, then mid list).
+// list / count: the two size classes k_order filled ([0 .. cap) small, [cap .. 2 cap) large)
+void mgk_facet_hash(hipStream_t st, const SelJob *jobs, const void *outs, const uint32_t *list, const uint32_t *count, uint32_t cap) {
+    if (!cap) return;
+    hipLaunchKernelGGL((k_facet_hash<MG_BLOCK>), dim3(cap < 768 ? cap : 768), dim3(MG_BLOCK), 0, st, jobs, (const SelOut *)outs, list, count, cap);
+    hipLaunchKernelGGL((k_facet_hash<1024>), dim3(cap < 256 ? cap : 256), dim3(1024), 0, st, jobs, (const SelOut *)outs, list + cap, count + 1, cap);
+}
 void mgk_select(hipStream_t st, const SelJob *jobs, const void *outs, uint32_t njobs, uint32_t max_m, int passes, int finals,
                 void *items_mem, uint32_t cap_items, uint32_t *counters, uint32_t *fin_list) {
     if (!njobs) return;

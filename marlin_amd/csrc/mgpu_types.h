@@ -76,7 +76,14 @@ struct SelJob {                      // one top-k selection (rank keys of a sque
     // (0xFFFFFFFF - gen_hist[b], b) with b = gen_touched[i], emitted as gen_ord2id[b]; key_hi/key_lo are then scratch
     // the selecting workgroup may fill; NULL = the keys are already in key_hi/key_lo
     const uint32_t *gen_touched, *gen_hist, *gen_ord2id;
+    // facet jobs of a directly counted field (SqDev::fdirect_mask) whose distinct values k_facet_hash counts in an LDS
+    // hash table straight from the hits' ordinals whenever the squery has at most MG_FHASH_MAX_M hits: no histogram
+    // is touched then (the rank kernel skips its atomics, k_select_first skips the job)
+    uint32_t fhash;
 };
+#define MG_FHASH_SMALL_M 1536u       // ... of which the 256-lane / 4096-slot size of k_facet_hash takes those up to here
+#define MG_FHASH_MAX_M 8192u         // most hits for which a sparse facet field is counted by hashing in LDS
+#define MG_FHASH_MAX_K 56u           // largest k of such a job (its merge buffer holds 9 k keys)
 #define MG_FAC_NONE   0xFFFFFFFFu     // fac_ord: the document has no value in the field
 #define MG_FAC_LOOKUP 0xFFFFFFFEu     // fac_ord: several values, or not staged: k_docproc reads the record / CSR itself
 #define MG_SEL_MID_KEYS 131072u      // longest fresh list one 1024-thread workgroup selects (k_select_mid)
@@ -134,6 +141,10 @@ struct SqDev {
     // then ARE the list of touched bins (with repeats, which the exchange in the key derivation turns into
     // zero counts), k_docproc skips the field and no touched list is built
     uint32_t fdirect_mask;
+    // bit f (a subset of fdirect_mask): with at most MG_FHASH_MAX_M hits the field is not counted into hist[f] at all,
+    // k_facet_hash counts it from fac_ord[f] (SelJob::fhash)
+    uint32_t fhash_mask;
+    uint32_t fhash_njobs, fhash_jobs[4];   // the select jobs of those fields (k_order hands them to k_facet_hash by hit count)
     int32_t  fac_in_rank;            // the rank kernel leaves every hit's facet ordinals in fac_ord while it holds the records
     uint32_t *fac_ord[MGPU_MAX_FIELDS];   // [hit_cap] per histogram field: the hit's ordinal, MG_FAC_NONE, or MG_FAC_LOOKUP
     uint32_t *hist[MGPU_MAX_FIELDS]; // [fa_nord[f]] zeroed per query
