@@ -34,7 +34,7 @@ enum {
     MGPU_E_ARG = -2,          /* malformed argument */
     MGPU_E_LIMIT = -3,        /* beyond a documented limit of this implementation */
     MGPU_E_SCRATCH = -4,      /* position scratch pool exhausted (raise mgpu_ctx_create's pool) */
-    MGPU_E_UNSUPPORTED = -5   /* e.g. R_GEO rule, fast-rank mode */
+    MGPU_E_UNSUPPORTED = -5   /* e.g. R_GEO rule; fast-rank where the reference itself misbehaves (see mgpu_plan_t) */
 };
 
 /* sort.h:7-18 */
@@ -122,7 +122,8 @@ typedef struct mgpu_plan {
     int32_t  num_terms;                         /* 0, 1, 3 or 2n (query.c:489-603) */
     int32_t  num_words;
     uint32_t term_npost[MGPU_MAX_TERMS];
-    const uint32_t *term_post[MGPU_MAX_TERMS];  /* pids */
+    const uint32_t *term_post[MGPU_MAX_TERMS];  /* pids; the postings of words at distance 0 come FIRST ... */
+    uint32_t term_nzero[MGPU_MAX_TERMS];        /* ... this many of them: termdata[t].tzero_typo_bmap (squery.c:107-113) */
     uint16_t exact_present;                     /* bit i: exact_docid_map[i] != NULL */
     /* wid table */
     uint32_t num_wids;
@@ -139,6 +140,17 @@ typedef struct mgpu_plan {
     int32_t  rank_by;
     int32_t  rank_asc;
     int32_t  rules[MGPU_MAX_RULES];             /* q->rank_rule, MGPU_R_DONE terminated */
+    /* perform_ranking's switch (docrank.c:565-587): with full_scan == 0, rank_by >= 0 and more hits than the threshold the
+     * shard is ranked on a sample (perform_fast_ranking, docrank.c:478-560: zero-typo documents first, then the first
+     * 1000 in num_dbi[rank_by] order, then every n-th document) and the facet counts of the top 2N are recounted exactly
+     * (squery.c:398-408,439-446); mgpu_sqout_t.fast_rank reports it.  Needs facet_pid_base when facets are enabled.
+     * MGPU_E_UNSUPPORTED where the reference itself misbehaves in this mode: a cardinality aggregation (NULL
+     * dereference, metric-aggs.c:23-45); MGPU_E_LIMIT when the sample outgrows the reference's rank buffer
+     * (docrank.c:491) or rank_by is a field with several values per document. */
+    int32_t  full_scan;
+    uint32_t full_scan_threshold;
+    uint32_t facet_pid_base[MGPU_MAX_FIELDS];   /* pid of facetid2bmap[smallest facet id of field f]; the field's other
+                                                 * ids follow in ascending id order.  0 = not given */
     /* aggs (metric-aggs.h) */
     int32_t  num_aggs;
     int32_t  agg_type[MGPU_MAX_AGGS];
@@ -172,6 +184,7 @@ typedef struct mgpu_sqout {      /* struct squery_result (squery.h:34-46), flat;
     int32_t   rcount[MGPU_MAX_FIELDS];           /* fh[f].rcount */
     mgpu_facet_t *fc[MGPU_MAX_FIELDS];           /* top 2*maxFacetResults by count, ties by facet id */
     mgpu_agg_out_t aggs[MGPU_MAX_AGGS];
+    int32_t   fast_rank;                         /* sq->fast_rank: the shard was ranked on a sample */
     uint64_t *dbg_docid_map; uint32_t dbg_words;
     mgpu_rank_t *dbg_all_ranks;
 } mgpu_sqout_t;

@@ -27,7 +27,10 @@ void mgk_rank(hipStream_t st, const SqDev *sqs, const uint32_t *blob, uint32_t m
               uint32_t max_tab_slots, const uint2 *tile_list, const uint32_t *tile_count, uint32_t tile_cap,
               unsigned long long *pool, uint32_t *pool_used, uint64_t pool_cap);
 void mgk_docproc(hipStream_t st, const SqDev *sqs, uint32_t nsq, const uint2 *tile_list, const uint32_t *tile_count,
-                 uint32_t tile_cap, uint32_t lds_bins);
+                 uint32_t tile_cap, uint32_t lds_bins, int pre);
+void mgk_fast_build(hipStream_t st, const SqDev *sqs, uint32_t nsq, const uint32_t *elig_list, uint32_t nelig,
+                    uint2 *tile_list_b, uint32_t *tile_count_b);
+void mgk_facet_recount(hipStream_t st, const SqDev *sqs, const void *jobs, uint32_t njobs);
 void mgk_fkeys(hipStream_t st, const void *jobs, uint32_t njobs, uint32_t max_n);
 void mgk_card(hipStream_t st, const void *jobs, uint32_t njobs, uint32_t max_n);
 void mgk_check_zero(hipStream_t st, const void *p, size_t bytes, uint32_t *flag);
@@ -55,6 +58,7 @@ struct FkJob { const uint32_t *hist; const uint32_t *ord2id; const uint32_t *tou
 struct CardJob { const uint32_t *ord2id; const uint32_t *touched; const uint32_t *ntouched; uint32_t *out_ids; uint32_t *out_n;
                  uint32_t *clean_hist; };   // histogram to put back to zero (fields no facet job consumes), or NULL
 struct SelOut { u64 *out_hi, *out_lo; uint32_t *out_pl; const uint32_t *payload; };
+struct RecountJob { uint32_t sq; uint32_t field; u64 *out_hi; const u64 *out_lo; const uint32_t *out_n; };
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
@@ -77,6 +81,7 @@ struct mgpu_shard {
     std::vector<uint32_t> post_winbase; // per pid: base into post_win, or ~0 (dense, empty or short posting)
     uint32_t fac_single = 0;            // bit f: every document has <= 1 value in facet field f, and every facet section is staged whole by the rank kernel
     uint64_t np_n[MGPU_MAX_FIELDS];
+    uint32_t np_multi = 0;              // bit i: some document appears more than once in num_dbi[i] (a list-valued field)
     double avg_dw;                      // mean docword entries per doc
     double avg_fv[MGPU_MAX_FIELDS];     // mean facet values per doc
     uint32_t n_dense;
@@ -397,6 +402,16 @@ static int shard_create_impl(int device, const mgpu_shard_desc_t *d, mgpu_shard_
         s->np_n[i] = d->np_n[i];
         std::vector<uint32_t> v(d->np_doc[i], d->np_doc[i] + d->np_n[i]);
         if ((rc = upload(s, v, &sd.np_doc[i]))) { mgpu_shard_destroy(s); return rc; }
+        // what fast-rank mode needs to know about the field: which idnum2dbl groups exist, and whether a document has
+        // several values
+        std::vector<uint64_t> grp(((size_t)N / 1000 + 64) / 64, 0), seen(sd.W ? sd.W : 1, 0);
+        for (uint32_t doc : v) {
+            if (doc >= N) { mgpu_shard_destroy(s); return fail(MGPU_E_ARG, "num_dbi docid beyond max_docid"); }
+            grp[(doc / 1000) >> 6] |= 1ull << ((doc / 1000) & 63);
+            if ((seen[doc >> 6] >> (doc & 63)) & 1ull) s->np_multi |= 1u << i;
+            seen[doc >> 6] |= 1ull << (doc & 63);
+        }
+        if ((rc = upload(s, grp, &sd.grp_has[i]))) { mgpu_shard_destroy(s); return rc; }
     }
     *out = s;
     return MGPU_OK;
@@ -530,6 +545,7 @@ struct Bump {
 // result header copied back per squery
 struct ResHdr {
     uint32_t num_hits, err, ovf_cnt, rank_n;
+    uint32_t fast_flag, total_hits, num_rank, pad0;      // fast-rank: SqDev::fast_flag / total_hits / num_rank
     uint32_t fac_n[MGPU_MAX_FIELDS];
     uint32_t card_n[MGPU_MAX_AGGS];
     AggPart agg[MGPU_MAX_AGGS];
@@ -557,6 +573,8 @@ struct JobFix { int sq; int kind; int field; };       // kind 0 rank, 1 facet
 struct Offs {      // arena offsets per squery (zero or nonzero region relative)
     size_t rows, hist[MGPU_MAX_FIELDS], touched[MGPU_MAX_FIELDS], ntouched[MGPU_MAX_FIELDS], facord[MGPU_MAX_FIELDS], andor, ovfcnt, docmap, win, rawcnt, hitsraw, hits, khi, klo, ovfl, aggpart;
     size_t fkhi[MGPU_MAX_FIELDS], fklo[MGPU_MAX_FIELDS];
+    size_t dbmap;
+    int aux_index;       // fast-eligible squery: index of its zero-typo twin in the batch, else -1
 };
 struct SelOff { size_t cand0, cand1, hist, ctl, outidx, andor; uint32_t mcap; };
 struct Pending {
@@ -579,6 +597,10 @@ struct Pending {
     size_t res_bytes = 0, nz_base = 0, up_bytes = 0, up_base = 0, up_sel = 0, up_selout = 0;
     uint32_t max_selm = 0;
     bool fuse_fk = false, prof = false;
+    int n_all = 0;                               // n plus the zero-typo twins of the fast-eligible squeries
+    std::vector<int> aux_parent;
+    std::vector<uint32_t> elig_list;
+    std::vector<RecountJob> recount;
     int nev = 0;                                 // events recorded (profiling)
     double t_begin = 0, t_lowered = 0;
 };
@@ -692,9 +714,13 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
     P.n = n; P.shards = shards; P.plans = plans;
 
     // ---------------- lower plans into host staging ----------------
-    P.sqd.resize(n);                                       // every element is memset below
+    P.sqd.resize(2 * (size_t)n);                           // room for a zero-typo twin per squery; every used element is memset below
     SqDev *sqd = P.sqd.data();
-    std::vector<SqHost> &sqh = P.sqh; sqh.resize(n);
+    std::vector<SqHost> &sqh = P.sqh; sqh.resize(2 * (size_t)n);
+    std::vector<int> &aux_parent = P.aux_parent; aux_parent.clear();
+    std::vector<uint32_t> &elig_list = P.elig_list; elig_list.clear();
+    std::vector<RecountJob> &recount = P.recount; recount.clear();
+    int n_all = n;
     std::vector<uint32_t> &blob = P.blob; blob.clear();
     std::vector<PendingScatter> &pscat = P.pscat; pscat.clear();
     std::vector<SelJob> &seljobs = P.seljobs; std::vector<SelOut> &selouts = P.selouts;
@@ -706,16 +732,20 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
     Bump zer;          // rest of the zero region
     Bump nz;           // non-zero region
     Bump cln;          // self-cleaned pool (its own allocation, see mgpu_ctx)
-    std::vector<int> &nrows = P.nrows; nrows.assign(n, 0);
+    std::vector<int> &nrows = P.nrows; nrows.assign(2 * (size_t)n, 0);
     uint32_t max_nblk = 1, max_N = 1, max_pblocks = 1, max_fk = 1, max_selm = 1, max_tab = 1, max_fac_k = 0, max_fac_nord = 0, max_lds_bins = 0;
     bool sel_wide = false;            // some selection may need the wide (many-workgroup) passes or the stand-alone sorts
 
-    std::vector<Offs> &offs = P.offs; offs.resize(n);
+    std::vector<Offs> &offs = P.offs; offs.resize(2 * (size_t)n);
     std::vector<SelOff> &seloff = P.seloff; seloff.clear();
     std::vector<uint32_t> &sl = P.sl, &dl = P.dl, &fo = P.fo, &pl = P.pl;
-    for (int i = 0; i < n; i++) {
-        const mgpu_plan_t &p = plans[i];
-        mgpu_shard *sh = shards[i];
+    for (int i = 0; i < n_all; i++) {
+        // i >= n: the zero-typo twin of squery aux_parent[i - n] (get_matching_zero_typo_docids, squery.c:280-328): the
+        // same formula over the postings of the distance-0 words only, no filter; nothing but its bitmap is wanted
+        const bool aux = i >= n;
+        const int pi = aux ? aux_parent[i - n] : i;
+        const mgpu_plan_t &p = plans[pi];
+        mgpu_shard *sh = shards[pi];
         if (!sh || sh->device != c->device) return fail(MGPU_E_ARG, "shard not on the context's device");
         if (p.num_terms < 0 || p.num_terms > MGPU_MAX_TERMS || p.num_words > MGPU_MAX_WORDS)
             return fail(MGPU_E_LIMIT, "too many query terms or words");
@@ -725,7 +755,9 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
         q.sh = sh->dev;
         const ShardDev &sd = sh->dev;
         q.num_words = p.num_words;
-        q.empty = (p.has_filter && p.filter_null) ? 1 : 0;
+        q.empty = (!aux && p.has_filter && p.filter_null) ? 1 : 0;
+        q.aux = aux ? 1 : 0;
+        offs[i].aux_index = -1;
         q.nblk = (sd.W + MG_WORDS_PER_BLOCK - 1) / MG_WORDS_PER_BLOCK;
         max_nblk = std::max(max_nblk, q.nblk);
         h.formula_rows = 0; h.scatter_docs = 0; h.sparse_docs = 0;
@@ -776,7 +808,9 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
                 const int row = -1;
                 uint64_t tc = 0;
                 q.term_sl[t] = (uint32_t)(sl.size() / 4);
-                for (uint32_t j = 0; j < p.term_npost[t]; j++) {
+                if (p.term_nzero[t] > p.term_npost[t]) return fail(MGPU_E_ARG, "term_nzero above term_npost");
+                const uint32_t npost_t = aux ? p.term_nzero[t] : p.term_npost[t];
+                for (uint32_t j = 0; j < npost_t; j++) {
                     int rc = use_term_posting(p.term_post[t][j], t, &dl);
                     if (rc) return rc;
                     tc += sh->post_card[p.term_post[t][j]];
@@ -811,8 +845,24 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
             q.hit_cap = (uint32_t)std::min<uint64_t>(hb, sd.N);
             max_N = std::max(max_N, q.hit_cap);
         }
+        // perform_ranking's switch (docrank.c:565-587): could this squery be ranked on a sample?
+        if (!aux && !p.full_scan && p.rank_by >= 0 && q.hit_cap > p.full_scan_threshold) {
+            if (p.rank_by >= sd.num_numbers) return fail(MGPU_E_ARG, "rank_by field out of range");
+            q.fast_eligible = 1; q.fast_thresh = p.full_scan_threshold; q.rank_asc = p.rank_asc ? 1 : 0;
+            q.np_rank = sd.np_doc[p.rank_by]; q.np_rank_n = sh->np_n[p.rank_by];
+            if ((sh->np_multi >> p.rank_by) & 1u) q.fast_bad |= 2;
+            for (int a = 0; a < p.num_aggs && a < MGPU_MAX_AGGS; a++) if (p.agg_type[a] == MGPU_A_CARDINALITY) q.fast_bad |= 1;
+            for (int f = 0; f < sd.num_facets; f++) {
+                q.fac_pid_base[f] = p.facet_pid_base[f];
+                if (p.max_facet_results > 0 && ((p.facet_enabled >> f) & 1u) && sd.fa_nord[f] && !p.facet_pid_base[f]) q.fast_bad |= 4;
+            }
+            offs[i].aux_index = n_all;
+            aux_parent.push_back(i);
+            elig_list.push_back((uint32_t)i);
+            n_all++;
+        }
         // filter program
-        if (p.has_filter && !p.filter_null) {
+        if (!aux && p.has_filter && !p.filter_null) {
             int depth = 0;
             q.fops_off = (uint32_t)blob.size();
             q.num_fops = p.num_fops;
@@ -871,6 +921,16 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
             while (blob.size() & 3) blob.push_back(0);       // the list table is read as uint4
             q.sl_off = (uint32_t)blob.size();
             blob.insert(blob.end(), sl.begin(), sl.end());
+        }
+        if (aux) {
+            // nothing downstream of the formula looks at a twin: bitmap + count only
+            q.do_rank = -1; q.rank_by = -1; q.nproc_blocks = 1;
+            Offs &o = offs[i];
+            h.hdr_off = res.take(sizeof(ResHdr));
+            o.docmap = nz.take((size_t)sd.Wp * 8);
+            o.win = nz.take((size_t)((q.nblk + 1) / 2) * sizeof(uint2)); o.rawcnt = zer.take(4, 4);
+            o.andor = zer.take(32); o.ovfcnt = zer.take(4);
+            continue;
         }
         // wid table
         {
@@ -950,7 +1010,8 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
         }
         o.andor = zer.take(32); o.ovfcnt = zer.take(4);
         // the dense docid_map exists only for the parity capture (k_formula emits the hits itself)
-        o.docmap = (p.capture & 1) ? nz.take((size_t)sd.Wp * 8) : (size_t)-1;
+        o.docmap = ((p.capture & 1) || q.fast_eligible) ? nz.take((size_t)sd.Wp * 8) : (size_t)-1;
+        if (q.fast_eligible) o.dbmap = nz.take((size_t)sd.Wp * 8);
         if ((q.nblk + 1) / 2 > MG_ORDER_WINDOWS) return fail(MGPU_E_LIMIT, "shard larger than 2048 formula windows (67M docids)");
         o.win = nz.take((size_t)((q.nblk + 1) / 2) * sizeof(uint2)); o.rawcnt = zer.take(4, 4);
         const size_t hc = std::max<size_t>(q.hit_cap, 1);
@@ -1005,6 +1066,9 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
     const size_t off_tilecnt = zer.take(4, 4);
     const size_t off_todocnt = zer.take(8 * 4, 8);            // select work-list counters
     const size_t off_tiles = nz.take(std::max<size_t>(tile_cap, 1) * sizeof(uint2));
+    // batches with fast-eligible squeries: a second work list, built once the samples are known
+    const size_t off_tilecnt_b = zer.take(4, 4);
+    const size_t off_tiles_b = elig_list.empty() ? 0 : nz.take(std::max<size_t>(tile_cap, 1) * sizeof(uint2));
     const size_t off_todo = nz.take(2 * (seloff.size() + 1) * 4);                         // final list, mid list
     const size_t off_fhcnt = zer.take(2 * 4, 8);                                          // k_facet_hash job lists: counters ...
     const size_t off_fhlist = nz.take(2 * (seloff.size() + 1) * 4);                       // ... and the two lists
@@ -1025,7 +1089,7 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
     const size_t nz_bytes = (nz.off + 255) / 256 * 256;
     // upload region layout
     Bump up;
-    const size_t up_sq = up.take(sizeof(SqDev) * n);
+    const size_t up_sq = up.take(sizeof(SqDev) * (size_t)n_all);
     const size_t up_blob = up.take(std::max<size_t>(blob.size(), 1) * 4);
     size_t nitems = 0;
     for (auto &ps : pscat) nitems += (ps.n + MG_SCATTER_CHUNK - 1) / MG_SCATTER_CHUNK;
@@ -1036,6 +1100,10 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
     for (int i = 0; i < n; i++) { nfk += sqh[i].nfac; ncard += sqh[i].ncard; }
     const size_t up_fk = up.take(std::max<size_t>(nfk, 1) * sizeof(FkJob));
     const size_t up_card = up.take(std::max<size_t>(ncard, 1) * sizeof(CardJob));
+    size_t nfac_elig = 0;
+    for (uint32_t e : elig_list) nfac_elig += sqh[e].nfac;
+    const size_t up_elig = up.take(std::max<size_t>(elig_list.size(), 1) * 4);
+    const size_t up_recount = up.take(std::max<size_t>(nfac_elig, 1) * sizeof(RecountJob));
     const size_t up_bytes = (up.off + 255) / 256 * 256;
     const size_t up_base = nz_base + nz_bytes;
     const size_t total = up_base + up_bytes;
@@ -1061,9 +1129,26 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
     char *UP = A + up_base;
 
     // fix up device pointers
+    for (int i = n; i < n_all; i++) {                      // the zero-typo twins
+        SqDev &q = sqd[i]; SqHost &h = sqh[i]; Offs &o = offs[i];
+        ResHdr *hdr = (ResHdr *)(R + h.hdr_off);
+        q.rows = nullptr;
+        q.docid_map = (uint64_t *)(NZ + o.docmap);
+        q.win_info = (uint2 *)(NZ + o.win); q.raw_count = (uint32_t *)(Z + o.rawcnt); q.hits_raw = nullptr; q.hits = nullptr;
+        q.num_hits = &hdr->num_hits; q.err = &hdr->err; q.ovf_cnt = (uint32_t *)(Z + o.ovfcnt);
+        q.key_andor = (uint64_t *)(Z + o.andor);
+    }
     for (int i = 0; i < n; i++) {
         SqDev &q = sqd[i]; SqHost &h = sqh[i]; Offs &o = offs[i];
         ResHdr *hdr = (ResHdr *)(R + h.hdr_off);
+        if (q.fast_eligible) {
+            const SqDev &tw = sqd[o.aux_index];
+            q.zmap = (const uint64_t *)(NZ + offs[o.aux_index].docmap);
+            q.z_count = &((ResHdr *)(R + sqh[o.aux_index].hdr_off))->num_hits;
+            (void)tw;
+            q.dbmap = (uint64_t *)(NZ + o.dbmap);
+            q.fast_flag = &hdr->fast_flag; q.total_hits = &hdr->total_hits; q.num_rank = &hdr->num_rank;
+        }
         q.rows = (uint64_t *)(Z + o.rows);
         q.docid_map = o.docmap == (size_t)-1 ? nullptr : (uint64_t *)(NZ + o.docmap);
         q.win_info = (uint2 *)(NZ + o.win); q.raw_count = (uint32_t *)(Z + o.rawcnt); q.hits_raw = (uint32_t *)(NZ + o.hitsraw);
@@ -1121,7 +1206,7 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
         sj.hist = (uint32_t *)(CL + so.hist); sj.ctl = (uint32_t *)(Z + so.ctl);
         sj.out_idx = (uint32_t *)(NZ + so.outidx); sj.m_cap = so.mcap;
         if (jf.kind == 0) {
-            sj.key_hi = q.key_hi; sj.key_lo = q.key_lo; sj.m_ptr = q.num_hits; sj.k = h.k;
+            sj.key_hi = q.key_hi; sj.key_lo = q.key_lo; sj.m_ptr = q.fast_eligible ? q.num_rank : q.num_hits; sj.k = h.k;
             sj.out_n = &hdr->rank_n; sj.mask = q.key_andor; sj.skip_ones = 0;
             so2.out_hi = (u64 *)(R + h.rank_hi); so2.out_lo = (u64 *)(R + h.rank_lo);
             so2.out_pl = (uint32_t *)(R + h.rank_pl); so2.payload = q.hits;
@@ -1134,6 +1219,7 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
             sj.k = h.fac_k[jf.field]; sj.out_n = &hdr->fac_n[jf.field]; sj.mask = (const uint64_t *)(Z + so.andor); sj.skip_ones = 1;
             so2.out_hi = (u64 *)(R + h.fac_hi[jf.field]); so2.out_lo = (u64 *)(R + h.fac_lo[jf.field]);
             so2.out_pl = (uint32_t *)(R + h.fac_pl[jf.field]); so2.payload = nullptr;
+            if (q.fast_eligible) recount.push_back({(uint32_t)jf.sq, (uint32_t)f, so2.out_hi, so2.out_lo, &hdr->fac_n[jf.field]});
             FkJob fj; fj.hist = q.hist[f]; fj.ord2id = q.sh.fa_ord2id[f]; fj.touched = q.touched[f]; fj.ntouched = q.ntouched[f];
             fj.key_hi = (u64 *)q.fkey_hi[f]; fj.key_lo = (u64 *)q.fkey_lo[f];
             fj.andor = (u64 *)(Z + so.andor);
@@ -1169,7 +1255,9 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
         }
     }
     // staging copy
-    memcpy(c->pin + up_sq, sqd, sizeof(SqDev) * n);
+    memcpy(c->pin + up_sq, sqd, sizeof(SqDev) * (size_t)n_all);
+    if (!elig_list.empty()) memcpy(c->pin + up_elig, elig_list.data(), elig_list.size() * 4);
+    if (!recount.empty()) memcpy(c->pin + up_recount, recount.data(), recount.size() * sizeof(RecountJob));
     if (!blob.empty()) memcpy(c->pin + up_blob, blob.data(), blob.size() * 4);
     if (!items.empty()) memcpy(c->pin + up_items, items.data(), items.size() * sizeof(ScatterItem));
     if (!seljobs.empty()) { memcpy(c->pin + up_sel, seljobs.data(), seljobs.size() * sizeof(SelJob));
@@ -1217,12 +1305,22 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
     mark();
     uint2 *d_tiles = (uint2 *)(NZ + off_tiles); uint32_t *d_tilecnt = (uint32_t *)(Z + off_tilecnt);
     uint32_t *d_fhlist = (uint32_t *)(NZ + off_fhlist), *d_fhcnt = (uint32_t *)(Z + off_fhcnt);
-    mgk_formula(st, d_sq, d_blob, max_nblk, (uint32_t)n, d_tiles, d_tilecnt, (uint32_t)tile_cap, d_fhlist, d_fhcnt, nfhash);
+    mgk_formula(st, d_sq, d_blob, max_nblk, (uint32_t)n_all, d_tiles, d_tilecnt, (uint32_t)tile_cap, d_fhlist, d_fhcnt, nfhash);
+    if (!elig_list.empty()) {
+        // fast-rank (docrank.c:478-560): aggregations over ALL hits of the squeries k_order flagged, then their hit
+        // lists become the samples and the work list is rebuilt
+        bool any_aggs = false;
+        for (uint32_t e : elig_list) any_aggs |= sqd[e].num_aggs > 0;
+        if (any_aggs) mgk_docproc(st, d_sq, (uint32_t)n, d_tiles, d_tilecnt, (uint32_t)tile_cap, 0, 1);
+        mgk_fast_build(st, d_sq, (uint32_t)n, (const uint32_t *)(UP + up_elig), (uint32_t)elig_list.size(),
+                       (uint2 *)(NZ + off_tiles_b), (uint32_t *)(Z + off_tilecnt_b));
+        d_tiles = (uint2 *)(NZ + off_tiles_b); d_tilecnt = (uint32_t *)(Z + off_tilecnt_b);
+    }
     mark();
     tick();
     mgk_rank(st, d_sq, d_blob, max_N, (uint32_t)n, max_tab, d_tiles, d_tilecnt, (uint32_t)tile_cap, c->pool, c->pool_used, c->pool_cap);
     mark();
-    mgk_docproc(st, d_sq, (uint32_t)n, d_tiles, d_tilecnt, (uint32_t)tile_cap, max_lds_bins);
+    mgk_docproc(st, d_sq, (uint32_t)n, d_tiles, d_tilecnt, (uint32_t)tile_cap, max_lds_bins, 0);
     mark();
     tick();
     mgk_fkeys(st, UP + up_fk, (uint32_t)fkjobs.size(), max_fk);
@@ -1231,6 +1329,7 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
     mgk_facet_hash(st, (const SelJob *)(UP + up_sel), UP + up_selout, d_fhlist, d_fhcnt, nfhash);
     mgk_select(st, (const SelJob *)(UP + up_sel), UP + up_selout, (uint32_t)seljobs.size(), max_selm, MG_SEL_PASSES, 0,
                NZ + off_items, sel_wide ? sel_cap_items : 0u, (uint32_t *)(Z + off_todocnt), (uint32_t *)(NZ + off_todo));
+    mgk_facet_recount(st, d_sq, UP + up_recount, (uint32_t)recount.size());
     mark();
     tick();
     if (copy_mode == 0) HIPCHK(hipMemcpyAsync(c->pin_out, R, res_bytes, hipMemcpyDeviceToHost, st));
@@ -1302,8 +1401,12 @@ static int execute_end(mgpu_ctx_t *c, mgpu_sqout_t *outs, bool *completed) {
         SqHost &h = sqh[i]; SqDev &q = sqd[i]; mgpu_shard *sh = shards[i];
         mgpu_sqout_t &o = outs[i];
         const ResHdr *hdr = (const ResHdr *)(c->pin_out + h.hdr_off);
-        o.num_hits = hdr->num_hits;
-        if (hdr->err) { o.status = -(int)hdr->err; worst = o.status; g_err = hdr->err == (uint32_t)(-MGPU_E_LIMIT) ? "hit count above the planned bound" : "device reported an error (position scratch pool exhausted)"; continue; }
+        const bool fast = q.fast_eligible && hdr->fast_flag;
+        o.num_hits = fast ? hdr->total_hits : hdr->num_hits;
+        o.fast_rank = fast ? 1 : 0;
+        if (hdr->err) { o.status = -(int)hdr->err; worst = o.status; g_err = hdr->err == (uint32_t)(-MGPU_E_LIMIT) ? (fast ? "fast-rank: the sample outgrows the reference's rank buffer, or rank_by has several values per document" : "hit count above the planned bound")
+                                                                     : hdr->err == (uint32_t)(-MGPU_E_UNSUPPORTED) ? "fast-rank with a cardinality aggregation (the reference dereferences NULL there) or without facet_pid_base"
+                                                                     : "device reported an error (position scratch pool exhausted)"; continue; }
         const uint64_t M = hdr->num_hits;
         // ranks
         uint32_t rn = h.k ? hdr->rank_n : 0;
@@ -1342,7 +1445,7 @@ static int execute_end(mgpu_ctx_t *c, mgpu_sqout_t *outs, bool *completed) {
             o.dbg_docid_map = (uint64_t *)malloc(std::max<size_t>(q.sh.W, 1) * 8);
             HIPCHK(hipMemcpy(o.dbg_docid_map, A + h.docid_map_off, (size_t)q.sh.W * 8, hipMemcpyDeviceToHost));
         }
-        if ((p.capture & 2) && h.k) {
+        if ((p.capture & 2) && h.k && !fast) {
             std::vector<u64> khi(M), klo(M); std::vector<uint32_t> hits(M);
             if (M) {
                 HIPCHK(hipMemcpy(khi.data(), A + h.key_hi_off, M * 8, hipMemcpyDeviceToHost));

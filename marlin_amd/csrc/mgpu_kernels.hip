@@ -295,7 +295,7 @@ __global__ __launch_bounds__(MG_BLOCK) void k_formula(const SqDev *sqs, const ui
     uint32_t off = block_excl_scan(cnt, &tot, s_scan);
     if (threadIdx.x == 0) {
         uint32_t b = 0;
-        if (tot) {
+        if (tot && hits_raw) {                      // (a zero-typo twin has no hit list: its bitmap and count are all that is wanted)
             b = atomicAdd(raw_count, tot);
             if (b + tot > hit_cap) { atomicMax(err, (uint32_t)(-MGPU_E_LIMIT)); b = 0xFFFFFFFFu; }   // the host's bound was wrong
         }
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(MG_BLOCK) void k_formula(const SqDev *sqs, const ui
     }
     __syncthreads();
     const uint32_t rbase = red[0];
-    if (cnt && rbase != 0xFFFFFFFFu) {
+    if (cnt && hits_raw && rbase != 0xFFFFFFFFu) {
         off += rbase;
         emit_bits(v.a, w0 << 6, hits_raw, off); emit_bits(v.b, (w0 + 1) << 6, hits_raw, off);
     }
@@ -340,12 +340,22 @@ __global__ __launch_bounds__(MG_BLOCK) void k_order(const SqDev *sqs, uint2 *til
         __syncthreads();
     }
     uint32_t M = carry;
+    if (sp->aux) {                       // zero-typo twin: the count is the result
+        if (threadIdx.x == 0) *p_num_hits = M;
+        return;
+    }
     if (M > hit_cap || *p_err) {         // the host's bound was wrong (k_formula refused to write): report, touch no per-hit array
         if (threadIdx.x == 0) atomicMax(p_err, (uint32_t)(-MGPU_E_LIMIT));
         M = 0;
     }
     const uint32_t ntiles = (M + MG_BLOCK - 1) / MG_BLOCK;
-    if (threadIdx.x == 0) { *p_num_hits = M; s_tbase = ntiles ? atomicAdd(tile_count, ntiles) : 0; }
+    if (threadIdx.x == 0) {
+        *p_num_hits = M; s_tbase = ntiles ? atomicAdd(tile_count, ntiles) : 0;
+        if (sp->fast_eligible) {         // perform_ranking's switch (docrank.c:571)
+            *sp->total_hits = M; *sp->num_rank = M;
+            *sp->fast_flag = M > sp->fast_thresh ? 1u : 0u;
+        }
+    }
     const uint32_t nfh = sp->fhash_njobs;
     if (threadIdx.x < nfh && M <= MG_FHASH_MAX_M) {
         const uint32_t cls = M <= MG_FHASH_SMALL_M ? 0u : 1u;
@@ -381,6 +391,186 @@ __global__ __launch_bounds__(MG_BLOCK) void k_order_copy(const SqDev *sqs, const
             hits[x] = hits_raw[s_rbase[lo] + (x - s_obase[lo])];
         }
         __syncthreads();                                         // LDS is reused by the next work item
+    }
+}
+
+// ------------------------------------------------------------------ fast-rank: the sample (docrank.c:478-560)
+// perform_fast_ranking for one squery per workgroup (1024 lanes), run only when k_order set its fast_flag.  The hit
+// list (all matching documents, ascending) is REPLACED by the sample S in the order the reference ranks it:
+//   1. every zero-typo document when there are at most 1000 of them (ascending docids), else the zero-typo map becomes
+//      the "preferred map" rmap in place of docid_map -- unfiltered, as in the reference;
+//   2. documents of rmap in num_dbi[rank_by] order (reversed for ascending) not yet taken, until 1000 are in S (at
+//      least one is always taken: the reference tests the count after adding);
+//   3. every skip-th document of rmap in docid order that is not in S yet.
+// num_hits then counts S (what the rank and facet kernels walk), num_rank = |S| - 1 (docrank.c:550: the reference drops
+// the last ranked document from the sort), total_hits keeps the real hit count.
+#define FB_NT 1024
+__device__ __forceinline__ bool bm_bit(const u64 *m, uint32_t d) { return (m[d >> 6] >> (d & 63)) & 1ull; }
+__global__ __launch_bounds__(FB_NT) void k_fast_build(const SqDev *sqs, const uint32_t *list) {
+    const SqDev *sp = &sqs[list[blockIdx.x]];
+    if (!*sp->fast_flag) return;
+    __shared__ uint32_t lds[FB_NT / 64];
+    __shared__ uint32_t s_pos, s_taken, s_run;
+    const uint32_t W = sp->sh.W, N = sp->sh.N;
+    uint32_t *hits = sp->hits;
+    u64 *dbmap = (u64 *)sp->dbmap;
+    const u64 *D = (const u64 *)sp->docid_map, *Z = (const u64 *)sp->zmap;
+    if (sp->fast_bad) {
+        if (threadIdx.x == 0) {
+            atomicMax(sp->err, (uint32_t)(-((sp->fast_bad & 2) ? MGPU_E_LIMIT : MGPU_E_UNSUPPORTED)));
+            *sp->num_hits = 0; *sp->num_rank = 0;
+        }
+        return;
+    }
+    const uint32_t total = *sp->total_hits;
+    uint32_t fcount = total / 100 < 10000u ? total / 100 : 10000u;          // MIN(total / 100, MAX_HITS_LIMIT * 10)
+    if (fcount < 5000u) fcount = 5000u;                                      // MAX(.., MAX_HITS_LIMIT * 5)
+    const uint32_t cap = 1000u + fcount + 10u;                               // the reference's rank buffer (docrank.c:491)
+    const uint32_t skip = total / fcount + 1;
+    const uint32_t zt = *sp->z_count;
+    const u64 *rmap = D;
+    for (uint32_t w = threadIdx.x; w < W; w += FB_NT) dbmap[w] = 0;
+    if (threadIdx.x == 0) { s_pos = 0; s_run = 0; }
+    __syncthreads();
+    // 1. zero-typo documents
+    if (zt && zt <= 1000u) {
+        for (uint32_t base = 0; base < W; base += FB_NT) {
+            const uint32_t w = base + threadIdx.x;
+            const u64 x = w < W ? Z[w] : 0ull;
+            uint32_t tot;
+            uint32_t off = s_pos + block_excl_scan<FB_NT>((uint32_t)__popcll(x), &tot, lds);
+            if (x) { dbmap[w] = x; emit_bits(x, w << 6, hits, off); }
+            __syncthreads();
+            if (threadIdx.x == 0) s_pos += tot;
+            __syncthreads();
+        }
+    } else if (zt) rmap = Z;
+    __threadfence();
+    __syncthreads();
+    // 2. ranking order
+    {
+        const uint32_t *np = sp->np_rank; const uint64_t n = sp->np_rank_n;
+        const uint32_t r0 = s_pos;
+        const uint32_t take = r0 < 1000u ? 1000u - r0 : 1u;
+        if (threadIdx.x == 0) s_taken = 0;
+        __syncthreads();
+        for (uint64_t base = 0; base < n; base += 4 * FB_NT) {
+            if (s_taken >= take) break;                                       // uniform: read after the barrier below
+            uint32_t doc[4]; bool m[4]; uint32_t c = 0;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint64_t i = base + (uint64_t)threadIdx.x * 4 + u;
+                doc[u] = i < n ? np[sp->rank_asc ? n - 1 - i : i] : 0xFFFFFFFFu;
+                m[u] = false;
+                if (doc[u] < N && bm_bit(rmap, doc[u])) {
+                    const u64 dbw = __hip_atomic_load(&dbmap[doc[u] >> 6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    m[u] = !((dbw >> (doc[u] & 63)) & 1ull);
+                }
+                c += m[u] ? 1u : 0u;
+            }
+            uint32_t tot;
+            uint32_t p = s_taken + block_excl_scan<FB_NT>(c, &tot, lds);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (!m[u]) continue;
+                if (p < take) { hits[r0 + p] = doc[u]; atomicOr(&dbmap[doc[u] >> 6], 1ull << (doc[u] & 63)); }
+                p++;
+            }
+            __threadfence();
+            __syncthreads();
+            if (threadIdx.x == 0) s_taken = s_taken + tot < take ? s_taken + tot : take;
+            __syncthreads();
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_pos = r0 + s_taken;
+        __syncthreads();
+    }
+    // 3. every skip-th document of rmap
+    bool over = false;
+    for (uint32_t base = 0; base < W; base += FB_NT) {
+        const uint32_t w = base + threadIdx.x;
+        const u64 x = w < W ? rmap[w] : 0ull;
+        uint32_t tot;
+        const uint32_t ord0 = s_run + block_excl_scan<FB_NT>((uint32_t)__popcll(x), &tot, lds);
+        // the bits of this word whose ordinal in rmap is a multiple of skip and that are not in S yet
+        u64 sel = 0;
+        if (x) {
+            const u64 db = __hip_atomic_load(&dbmap[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            u64 y = x; uint32_t o = ord0;
+            while (y) {
+                const int b = __ffsll((long long)y) - 1; y &= y - 1;
+                if (o % skip == 0 && !((db >> b) & 1ull)) sel |= 1ull << b;
+                o++;
+            }
+        }
+        uint32_t tot2;
+        uint32_t off = s_pos + block_excl_scan<FB_NT>((uint32_t)__popcll(sel), &tot2, lds);
+        if (s_pos + tot2 > cap) over = true;                                  // uniform
+        else if (sel) emit_bits(sel, w << 6, hits, off);
+        __syncthreads();
+        if (threadIdx.x == 0) { s_run += tot; if (!over) s_pos += tot2; }
+        __syncthreads();
+        if (over) break;
+    }
+    if (threadIdx.x == 0) {
+        if (over) {                      // the reference would write past its malloc here
+            atomicMax(sp->err, (uint32_t)(-MGPU_E_LIMIT));
+            *sp->num_hits = 0; *sp->num_rank = 0;
+        } else { *sp->num_hits = s_pos; *sp->num_rank = s_pos ? s_pos - 1 : 0; }
+    }
+}
+
+// after k_fast_build: the tile work list again, over the lists as they are now (samples for the fast-ranked squeries)
+__global__ __launch_bounds__(MG_BLOCK) void k_tiles_again(const SqDev *sqs, uint32_t nsq, uint2 *tile_list, uint32_t *tile_count) {
+    const uint32_t i = blockIdx.x * MG_BLOCK + threadIdx.x;
+    if (i >= nsq) return;
+    const SqDev *sp = &sqs[i];
+    if (sp->aux) return;
+    const uint32_t M = *sp->num_hits;
+    const uint32_t ntiles = (M + MG_BLOCK - 1) / MG_BLOCK;
+    if (!ntiles) return;
+    const uint32_t base = atomicAdd(tile_count, ntiles);
+    for (uint32_t t = 0; t < ntiles; t++) tile_list[base + t] = make_uint2(i, t);
+}
+
+// get_facet_totalcount (squery.c:398-408) for the facet lists of the fast-ranked squeries: the sampled count of every
+// listed id is replaced by |facetid2bmap[id, field] AND docid_map|.  One workgroup per (squery, field) list.
+struct RecountJob { uint32_t sq; uint32_t field; u64 *out_hi; const u64 *out_lo; const uint32_t *out_n; };
+__global__ __launch_bounds__(MG_BLOCK) void k_facet_recount(const SqDev *sqs, const RecountJob *jobs) {
+    const RecountJob j = jobs[blockIdx.x];
+    const SqDev *sp = &sqs[j.sq];
+    if (!*sp->fast_flag) return;
+    uint32_t n = *j.out_n;
+    if (n == 0xFFFFFFFFu) return;                                             // selection unfinished: the host reports it
+    __shared__ uint32_t red[MG_BLOCK / 64];
+    const uint32_t f = j.field, nord = sp->sh.fa_nord[f], W = sp->sh.W, Wp = sp->sh.Wp;
+    const uint32_t *ord2id = sp->sh.fa_ord2id[f];
+    const u64 *D = (const u64 *)sp->docid_map;
+    for (uint32_t x = 0; x < n; x++) {
+        const uint32_t id = (uint32_t)j.out_lo[x];
+        uint32_t lo = 0, hi = nord;                                           // the id's ordinal: ord2id is ascending
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (ord2id[mid] < id) lo = mid + 1; else hi = mid; }
+        const uint32_t pid = sp->fac_pid_base[f] + lo;
+        uint32_t c = 0;
+        if (lo < nord && ord2id[lo] == id && pid < sp->sh.num_postings) {
+            const int32_t di = sp->sh.post_dense[pid];
+            if (di >= 0) {
+                const u64 *row = (const u64 *)sp->sh.dense + (size_t)di * Wp;
+                for (uint32_t w = threadIdx.x; w < W; w += MG_BLOCK) c += (uint32_t)__popcll(row[w] & D[w]);
+            } else {
+                const u64 a = sp->sh.post_off[pid], b = sp->sh.post_off[pid + 1];
+                for (u64 e = a + threadIdx.x; e < b; e += MG_BLOCK) c += bm_bit(D, sp->sh.post_doc[e]) ? 1u : 0u;
+            }
+        }
+        c = wave_sum32(c);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t t = 0;
+            for (int w2 = 0; w2 < MG_BLOCK / 64; w2++) t += red[w2];
+            j.out_hi[x] = (u64)(0xFFFFFFFFu - t);
+        }
+        __syncthreads();
     }
 }
 
@@ -950,7 +1140,10 @@ __global__ __launch_bounds__(MG_BLOCK) void k_rank_overflow(const SqDev *sqs, co
 // process_facet_result (docrank.c:371-389) and consume_*_agg (metric-aggs.c) over the hit list.
 // Facet ids were turned into dense ordinals by the mirror, so the hashtable of hashtable.c
 // becomes a histogram: privatised in LDS when the field has <= MG_LDS_HIST values.
-__global__ __launch_bounds__(MG_BLOCK) void k_docproc(const SqDev *sqs, const uint2 *tile_list, const uint32_t *tile_count, uint32_t lds_bins) {
+// pre: 1 = the pass BEFORE a fast-ranked squery's hit list is replaced by its sample: aggregations only, and only for
+// squeries whose fast_flag is set (calculate_agg over all matching documents, docrank.c:553-557); 0 = the normal pass,
+// in which those squeries count facets only (perform_doc_processing, docrank.c:409).
+__global__ __launch_bounds__(MG_BLOCK) void k_docproc(const SqDev *sqs, const uint2 *tile_list, const uint32_t *tile_count, uint32_t lds_bins, int pre) {
     uint32_t *hist = (uint32_t *)dyn_tab;        // lds_bins words of dynamic LDS: the largest field of the batch that is privatised
     __shared__ AggPart red[MG_BLOCK / 64];
     const uint32_t ntiles = *tile_count;
@@ -964,6 +1157,8 @@ __global__ __launch_bounds__(MG_BLOCK) void k_docproc(const SqDev *sqs, const ui
         // tiles beyond the slice count have nothing to add.
         const uint32_t nvb = sq.nproc_blocks, vb = item.y;
         if (vb >= nvb || (sq.hist_mask == 0 && sq.num_aggs == 0)) continue;
+        const bool fast = sq.fast_eligible && *sq.fast_flag;
+        if (pre && !(fast && sq.num_aggs)) continue;
         const bool have_ords = sq.fac_in_rank != 0;
         const uint32_t M = *sq.num_hits;
         const uint32_t stride = nvb * MG_BLOCK;
@@ -972,7 +1167,7 @@ __global__ __launch_bounds__(MG_BLOCK) void k_docproc(const SqDev *sqs, const ui
         const uint32_t *rec = sq.sh.rec;
         const uint32_t nnum_in = sq.sh.rec_nnum;
         for (int f = 0; f < sq.sh.num_facets; f++) {
-            if (!((sq.hist_mask >> f) & 1u) || ((sq.fdirect_mask >> f) & 1u)) continue;
+            if (pre || !((sq.hist_mask >> f) & 1u) || ((sq.fdirect_mask >> f) & 1u)) continue;
             const uint32_t nord = sq.sh.fa_nord[f];
             const uint32_t *off = sq.sh.fa_off[f];
             const uint32_t *ord = sq.sh.fa_ord[f];
@@ -1022,7 +1217,9 @@ __global__ __launch_bounds__(MG_BLOCK) void k_docproc(const SqDev *sqs, const ui
 
         for (int a = 0; a < sq.num_aggs; a++) {
             if (sq.agg_type[a] == MGPU_A_CARDINALITY) continue;
+            if (fast && !pre) continue;                  // aggregated before the sample replaced the hit list
             const uint32_t af = (uint32_t)sq.agg_field[a];
+            const uint64_t *grp = fast ? sq.sh.grp_has[af] : nullptr;    // fast mode reads idnum2dbl: a missing group = no value
             const double *col = sq.sh.num_col[af];
             const bool in_rec = af < nnum_in;
             double sum = 0.0, mn = 1.7976931348623157e308, mx = -1.7976931348623157e308;
@@ -1030,6 +1227,7 @@ __global__ __launch_bounds__(MG_BLOCK) void k_docproc(const SqDev *sqs, const ui
             for (uint32_t i = vb * MG_BLOCK + threadIdx.x; i < M; i += stride) {
                 const uint32_t d = sq.hits[i];
                 const double v = in_rec ? *(const double *)(rec + (size_t)d * S4 + 4 + 2 * af) : col[d];
+                if (grp && !((grp[(d / 1000u) >> 6] >> ((d / 1000u) & 63u)) & 1ull)) continue;
                 if (v != -1.7976931348623157e308) {          // get_num_value's "no value" marker, metric-aggs.c:106,149
                     sum += v; mn = v < mn ? v : mn; mx = v > mx ? v : mx; cnt++;
                 }
@@ -1057,10 +1255,12 @@ __global__ __launch_bounds__(MG_BLOCK) void k_docproc(const SqDev *sqs, const ui
 }
 
 // combines the per-slice partials in slice order; one wave per squery
-__global__ __launch_bounds__(64) void k_aggfinal(const SqDev *sqs) {
+__global__ __launch_bounds__(64) void k_aggfinal(const SqDev *sqs, int pre) {
     const SqDev &sq = sqs[blockIdx.x];
     const int a = threadIdx.x;
     if (a >= sq.num_aggs || sq.agg_type[a] == MGPU_A_CARDINALITY) return;
+    const bool fast = sq.fast_eligible && *sq.fast_flag;
+    if (fast != (pre != 0)) return;                  // a fast-ranked squery's partials belong to the pre-pass, the others' to the normal one
     const uint32_t M = *sq.num_hits;
     const uint32_t tiles = (M + MG_BLOCK - 1) / MG_BLOCK;
     const uint32_t nact = tiles < sq.nproc_blocks ? tiles : sq.nproc_blocks;
@@ -2179,6 +2379,16 @@ void mgk_formula(hipStream_t st, const SqDev *sqs, const uint32_t *blob, uint32_
     hipLaunchKernelGGL(k_order, dim3(nsq), dim3(MG_BLOCK), 0, st, sqs, tile_list, tile_count, fh_list, fh_count, fh_cap);
     hipLaunchKernelGGL(k_order_copy, dim3(worklist_grid(tile_cap)), dim3(MG_BLOCK), 0, st, sqs, tile_list, tile_count);
 }
+void mgk_fast_build(hipStream_t st, const SqDev *sqs, uint32_t nsq, const uint32_t *elig_list, uint32_t nelig,
+                    uint2 *tile_list_b, uint32_t *tile_count_b) {
+    if (!nelig) return;
+    hipLaunchKernelGGL(k_fast_build, dim3(nelig), dim3(FB_NT), 0, st, sqs, elig_list);
+    hipLaunchKernelGGL(k_tiles_again, dim3((nsq + MG_BLOCK - 1) / MG_BLOCK), dim3(MG_BLOCK), 0, st, sqs, nsq, tile_list_b, tile_count_b);
+}
+void mgk_facet_recount(hipStream_t st, const SqDev *sqs, const void *jobs, uint32_t njobs) {
+    if (!njobs) return;
+    hipLaunchKernelGGL(k_facet_recount, dim3(njobs), dim3(MG_BLOCK), 0, st, sqs, (const RecountJob *)jobs);
+}
 void mgk_rank(hipStream_t st, const SqDev *sqs, const uint32_t *blob, uint32_t max_n, uint32_t nsq,
               uint32_t max_tab_slots, const uint2 *tile_list, const uint32_t *tile_count, uint32_t tile_cap,
               unsigned long long *pool, uint32_t *pool_used, uint64_t pool_cap) {
@@ -2193,10 +2403,10 @@ void mgk_rank(hipStream_t st, const SqDev *sqs, const uint32_t *blob, uint32_t m
 // lds_bins: the largest histogram of the batch that has at most MG_LDS_HIST bins (those are privatised in LDS;
 // sizing the LDS by it instead of by the limit keeps more workgroups per CU when the small fields are small)
 void mgk_docproc(hipStream_t st, const SqDev *sqs, uint32_t nsq, const uint2 *tile_list, const uint32_t *tile_count,
-                 uint32_t tile_cap, uint32_t lds_bins) {
+                 uint32_t tile_cap, uint32_t lds_bins, int pre) {
     if (lds_bins > MG_LDS_HIST) lds_bins = MG_LDS_HIST;
-    hipLaunchKernelGGL(k_docproc, dim3(worklist_grid(tile_cap)), dim3(MG_BLOCK), (size_t)lds_bins * 4, st, sqs, tile_list, tile_count, lds_bins);
-    hipLaunchKernelGGL(k_aggfinal, dim3(nsq), dim3(64), 0, st, sqs);
+    hipLaunchKernelGGL(k_docproc, dim3(worklist_grid(tile_cap)), dim3(MG_BLOCK), (size_t)lds_bins * 4, st, sqs, tile_list, tile_count, lds_bins, pre);
+    hipLaunchKernelGGL(k_aggfinal, dim3(nsq), dim3(64), 0, st, sqs, pre);
 }
 void mgk_fkeys(hipStream_t st, const void *jobs, uint32_t njobs, uint32_t max_n) {
     if (!njobs) return;

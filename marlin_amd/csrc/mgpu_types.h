@@ -53,6 +53,9 @@ struct ShardDev {
     // numbers
     const double   *num_col[MGPU_MAX_FIELDS];   // [N]
     const uint32_t *np_doc[MGPU_MAX_FIELDS];
+    // idnum2dbl (sindex.c:528-565): bit g of grp_has[i] = some document of docids [1000 g, 1000 g + 1000) indexed a
+    // number of field i, i.e. the group's array exists (what get_num_value reads in fast-rank mode)
+    const uint64_t *grp_has[MGPU_MAX_FIELDS];
 };
 
 // layout of the packed 128-bit rank key: fields in rank-rule order, most significant first
@@ -158,6 +161,21 @@ struct SqDev {
     uint32_t nproc_blocks;
     // facet selection keys
     uint64_t *fkey_hi[MGPU_MAX_FIELDS], *fkey_lo[MGPU_MAX_FIELDS];
+    // ---- fast-rank (perform_fast_ranking, docrank.c:478-560) ----
+    int32_t  aux;                    // 1 = the zero-typo twin of a fast-eligible squery: only its docid_map and count are wanted
+    int32_t  fast_eligible;          // not full_scan and rank_by set: ranked on a sample when *total_hits > fast_thresh
+    uint32_t fast_thresh;
+    int32_t  rank_asc;
+    int32_t  fast_bad;               // what makes the mode impossible: 1 cardinality agg (-> MGPU_E_UNSUPPORTED),
+                                     // 2 rank_by field with several values per document, 4 facet postings unknown (-> MGPU_E_LIMIT / UNSUPPORTED)
+    const uint64_t *zmap;            // zero_typo_docid_map: the twin's docid_map
+    const uint32_t *z_count;         // its cardinality (the twin's num_hits word)
+    uint64_t *dbmap;                 // [Wp] documents already ranked
+    uint32_t *fast_flag;             // result word: 1 = the sample was ranked
+    uint32_t *total_hits;            // result word: num_hits of the squery when fast_flag (num_hits then counts the sample)
+    uint32_t *num_rank;              // device word: keys the rank selection looks at (sample size - 1, docrank.c:550)
+    const uint32_t *np_rank; uint64_t np_rank_n;    // num_dbi[rank_by] docids in key order
+    uint32_t fac_pid_base[MGPU_MAX_FIELDS];
     // ---- status ----
     uint32_t *err;                   // device word, nonzero = MGPU_E_* (negated)
 };

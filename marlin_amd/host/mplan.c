@@ -247,7 +247,7 @@ int mplan_from_terms(const mmirror_t *m, const m_query_t *q, m_termresult_t *tr,
             pl->term_post[t] = malloc(sizeof(uint32_t));
             if (n) {
                 pl->term_post[t][0] = m->W + tr[t].twid;
-                p->term_npost[t] = 1;
+                p->term_npost[t] = 1; p->term_nzero[t] = 1;          /* a twid matches with zero typos (squery.c:87-88) */
                 const uint32_t *wids;
                 uint64_t nw = mshard_twid_wids(s, tr[t].twid, &wids);
                 for (uint64_t i = 0; i < nw; i++) { m_u32map_set(&tr[t].wordids, wids[i], 0); m_u32map_set(&all, wids[i], 0); }
@@ -255,15 +255,18 @@ int mplan_from_terms(const mmirror_t *m, const m_query_t *q, m_termresult_t *tr,
             continue;
         }
         pl->term_post[t] = malloc(sizeof(uint32_t) * (tr[t].wordids.n ? tr[t].wordids.n : 1));
-        uint32_t np = 0;
+        uint32_t np = 0, nz = 0;
         for (uint32_t k = 0; k < tr[t].wordids.cap; k++) {
             uint32_t wid = tr[t].wordids.keys[k];
             if (!wid) continue;
             if (!mshard_wid_posting(s, wid, &docs)) continue;
             m_u32map_set(&all, wid, tr[t].wordids.vals[k]);
             pl->term_post[t][np++] = wid;
+            if (tr[t].wordids.vals[k] == 0) {                        /* zero typos: kept in front (tzero_typo_bmap) */
+                uint32_t x = pl->term_post[t][nz]; pl->term_post[t][nz] = wid; pl->term_post[t][np - 1] = x; nz++;
+            }
         }
-        p->term_npost[t] = np;
+        p->term_npost[t] = np; p->term_nzero[t] = nz;
     }
     for (int t = 0; t < q->num_terms; t++) p->term_post[t] = pl->term_post[t];
 
@@ -312,6 +315,8 @@ int mplan_from_terms(const mmirror_t *m, const m_query_t *q, m_termresult_t *tr,
     p->max_facet_results = q->cfg.max_facet_results;
     for (int f = 0; f < s->num_facets && f < 32; f++) if (q->cfg.facet_enabled[f]) p->facet_enabled |= 1u << f;
     p->rank_by = q->cfg.rank_by; p->rank_asc = q->cfg.rank_asc;
+    p->full_scan = q->cfg.full_scan ? 1 : 0; p->full_scan_threshold = q->cfg.full_scan_threshold;
+    for (int f = 0; f < s->num_facets && f < 32; f++) p->facet_pid_base[f] = m->fbase[f];
     for (int i = 0; i < MGPU_MAX_RULES; i++) p->rules[i] = q->rank_rule[i];
     p->num_aggs = q->num_aggs;
     for (int a = 0; a < q->num_aggs; a++) { p->agg_type[a] = q->aggs[a].type; p->agg_field[a] = q->aggs[a].field; }
@@ -408,8 +413,6 @@ int msq_submit_prepared(mgpu_ctx_t *ctx, const msq_prepared_t *pp) {
 static int sqout_to_result(const m_query_t *q, int sidx, int num_facets, mgpu_sqout_t *g, m_sqresult_t *o) {
     memset(o, 0, sizeof(*o));
     if (g->status) return g->status;
-    /* perform_ranking would have taken the sampled fast-rank path (docrank.c:571): not built yet */
-    if (!q->cfg.full_scan && g->num_hits > q->cfg.full_scan_threshold && q->cfg.rank_by >= 0) return MGPU_E_UNSUPPORTED;
     o->num_hits = g->num_hits;
     o->rank_count = g->rank_count;
     o->ranks = (m_docrank_t *)g->ranks; g->ranks = NULL;        /* identical 24-byte layout */
@@ -443,7 +446,7 @@ static int sqout_to_result(const m_query_t *q, int sidx, int num_facets, mgpu_sq
             default: break;
         }
     }
-    o->fast_rank = false;
+    o->fast_rank = g->fast_rank != 0;
     o->dbg_docid_map = g->dbg_docid_map; o->dbg_words = g->dbg_words; g->dbg_docid_map = NULL;
     o->dbg_all_ranks = (m_docrank_t *)g->dbg_all_ranks; g->dbg_all_ranks = NULL;
     return 0;

@@ -99,6 +99,7 @@ typedef struct {
     int num_aggs;
     uint32_t *card_buf[M_MAX_AGGS];
     uint64_t card_n[M_MAX_AGGS], card_cap[M_MAX_AGGS];
+    bool fast_rank;                     /* sq->fast_rank: perform_doc_processing leaves the aggs alone (docrank.c:409) */
 } ctx_t;
 
 static uint64_t *bm_new(const ctx_t *c) { return calloc(c->W ? c->W : 1, sizeof(uint64_t)); }
@@ -588,7 +589,117 @@ static void perform_doc_rank(ctx_t *c, m_docrank_t *rank) {
         }
     }
     if (q->cfg.rank_by >= 0) memcpy(&rank->compare, blob + 4 + (size_t)q->cfg.rank_by * 8, 8);
-    if (c->num_aggs) aggs_consume(c, blob);
+    if (c->num_aggs && !c->fast_rank) aggs_consume(c, blob);
+}
+
+static inline bool bm_test(const uint64_t *m, uint32_t d) { return (m[d >> 6] >> (d & 63)) & 1u; }
+static inline void bm_set(uint64_t *m, uint32_t d) { m[d >> 6] |= 1ull << (d & 63); }
+
+/* consume_*_agg with data == NULL (calculate_agg, docrank.c:445-448): the value comes from idnum2dbl, one array of
+ * 1000 doubles per (docid group, field) that exists once ANY document of the group indexed a number of that field
+ * (index_number, sindex.c:528-565) and is zero-filled otherwise; a group that does not exist yields "no value"
+ * (get_num_value, metric-aggs.c:105-142).  grp_has[field] = bitmap over the groups. */
+static void aggs_consume_fast(ctx_t *c, uint32_t docid, uint64_t *const *grp_has) {
+    const mshard_t *s = c->s;
+    for (int a = 0; a < c->num_aggs; a++) {
+        m_agg_t *ag = &c->aggs[a];
+        if (ag->type == MA_CARDINALITY) continue;                    /* refused before we get here */
+        if (!bm_test(grp_has[ag->field], docid / 1000)) continue;
+        double val = 0.0;
+        uint32_t bsz; const uint8_t *blob = mshard_docdata(s, docid, &bsz);
+        if (blob && bsz >= 4 + (size_t)(ag->field + 1) * 8) memcpy(&val, blob + 4 + (size_t)ag->field * 8, 8);
+        if (val == -DBL_MAX) continue;
+        switch (ag->type) {
+            case MA_MAX: if (val > ag->value) ag->value = val; break;
+            case MA_MIN: if (val < ag->value) ag->value = val; break;
+            case MA_AVG: ag->sum += val; ag->count++; break;
+            case MA_STATS:
+                ag->sum += val;
+                if (val < ag->min) ag->min = val;
+                if (val > ag->max) ag->max = val;
+                ag->count++;
+                break;
+            default: break;
+        }
+    }
+}
+
+/* perform_fast_ranking (docrank.c:478-560).  Returns the rank array (capacity as the reference mallocs it) and the
+ * count it reports, or NULL with *err set when the reference itself would misbehave: a cardinality agg (its consume
+ * dereferences the NULL data pointer, metric-aggs.c:23-45) or more sampled documents than its buffer holds. */
+static m_docrank_t *perform_fast_ranking(ctx_t *c, const uint64_t *docid_map, const uint64_t *zero_map,
+                                         uint32_t totalcount, uint32_t *resultcount, int *err) {
+    const m_query_t *q = c->q; const mshard_t *s = c->s;
+    *err = 0;
+    for (int a = 0; a < c->num_aggs; a++) if (c->aggs[a].type == MA_CARDINALITY) { *err = -5; return NULL; }
+    int fcount = (int)(totalcount / 100) < M_MAX_HITS_LIMIT * 10 ? (int)(totalcount / 100) : M_MAX_HITS_LIMIT * 10;
+    if (fcount < M_MAX_HITS_LIMIT * 5) fcount = M_MAX_HITS_LIMIT * 5;
+    const uint32_t cap = (uint32_t)(M_MAX_HITS_LIMIT + fcount + 10);
+    m_docrank_t *ranks = calloc(cap, sizeof(m_docrank_t));
+    uint64_t *dbmap = bm_new(c);
+    const uint64_t *rmap = docid_map;
+    uint32_t rankpos = 0;
+    uint64_t zt_card = orc_bm_cardinality(zero_map, c->W);
+    if (zt_card) {
+        if (zt_card <= M_MAX_HITS_LIMIT) {                           /* setup_zero_typo_ranks */
+            for (size_t w = 0; w < c->W; w++) {
+                uint64_t x = zero_map[w];
+                while (x) {
+                    int r = __builtin_ctzll(x); x &= x - 1;
+                    uint32_t d = (uint32_t)(w * 64 + (size_t)r);
+                    ranks[rankpos].docid = d; perform_doc_rank(c, &ranks[rankpos]); rankpos++;
+                    bm_set(dbmap, d);
+                }
+            }
+        } else rmap = zero_map;
+    }
+    /* documents in ranking order: num_dbi[rank_by] first to last, or last to first for ascending (MDB_LAST / MDB_PREV) */
+    {
+        const int f = q->cfg.rank_by;
+        const uint64_t n = s->np_n[f];
+        for (uint64_t i = 0; i < n; i++) {
+            uint32_t d = s->np_doc[f][q->cfg.rank_asc ? n - 1 - i : i];
+            if (d > s->max_docid || !bm_test(rmap, d)) continue;
+            if (bm_test(dbmap, d)) continue;
+            ranks[rankpos].docid = d; perform_doc_rank(c, &ranks[rankpos]);
+            bm_set(dbmap, d);
+            rankpos++;
+            if (rankpos >= M_MAX_HITS_LIMIT) break;
+        }
+    }
+    /* the rest: every skip_count-th document of rmap in docid order (setup_skip_ranks) */
+    {
+        const uint32_t skip_count = totalcount / (uint32_t)fcount + 1;
+        uint32_t counter = 0;
+        for (size_t w = 0; w < c->W && !*err; w++) {
+            uint64_t x = rmap[w];
+            while (x) {
+                int r = __builtin_ctzll(x); x &= x - 1;
+                uint32_t d = (uint32_t)(w * 64 + (size_t)r);
+                if (counter++ % skip_count != 0) continue;
+                if (bm_test(dbmap, d)) continue;
+                if (rankpos >= cap) { *err = -3; break; }            /* the reference writes past its malloc here */
+                ranks[rankpos].docid = d; perform_doc_rank(c, &ranks[rankpos]); rankpos++;
+            }
+        }
+    }
+    free(dbmap);
+    if (*err) { free(ranks); return NULL; }
+    *resultcount = rankpos - 1;                                      /* docrank.c:550: the last ranked document is dropped */
+    if (c->num_aggs) {                                               /* aggregates over ALL matching documents */
+        uint64_t *grp_has[M_MAX_FIELDS];
+        const size_t gw = ((size_t)s->max_docid / 1000 + 64) / 64;
+        for (int i = 0; i < s->num_numbers; i++) {
+            grp_has[i] = calloc(gw, sizeof(uint64_t));
+            for (uint64_t k = 0; k < s->np_n[i]; k++) bm_set(grp_has[i], s->np_doc[i][k] / 1000);
+        }
+        for (size_t w = 0; w < c->W; w++) {
+            uint64_t x = docid_map[w];
+            while (x) { int r = __builtin_ctzll(x); x &= x - 1; aggs_consume_fast(c, (uint32_t)(w * 64 + (size_t)r), grp_has); }
+        }
+        for (int i = 0; i < s->num_numbers; i++) free(grp_has[i]);
+    }
+    return ranks;
 }
 
 static int cmp_u32(const void *a, const void *b) {
@@ -624,25 +735,32 @@ int orc_execute_squery(const mshard_t *s, const m_query_t *q, int shard_idx, int
     uint32_t num_hits = (uint32_t)orc_bm_cardinality(docid_map, c->W);
     out->num_hits = num_hits;
     int rc = 0;
-    /* perform_ranking (docrank.c:565-587): full scan only */
-    if (!q->cfg.full_scan && num_hits > q->cfg.full_scan_threshold && q->cfg.rank_by >= 0) { rc = -2; goto done; }
-
-    m_docrank_t *ranks = malloc((num_hits ? num_hits : 1) * sizeof(m_docrank_t));
-    memset(ranks, 0, (num_hits ? num_hits : 1) * sizeof(m_docrank_t));   /* malloc garbage in the reference */
-    uint32_t rp = 0;
-    for (size_t w = 0; w < c->W; w++) {                              /* bmap_iterate -> setup_ranks */
-        uint64_t x = docid_map[w];
-        while (x) {
-            int r = __builtin_ctzll(x);
-            x &= x - 1;
-            ranks[rp].docid = (uint32_t)(w * 64 + (size_t)r);
-            perform_doc_rank(c, &ranks[rp]);
-            rp++;
+    /* perform_ranking (docrank.c:565-587) */
+    m_docrank_t *ranks;
+    uint32_t resultcount = num_hits;
+    c->fast_rank = !q->cfg.full_scan && num_hits > q->cfg.full_scan_threshold && q->cfg.rank_by >= 0;
+    out->fast_rank = c->fast_rank;
+    if (c->fast_rank) {
+        ranks = perform_fast_ranking(c, docid_map, zero_map, num_hits, &resultcount, &rc);
+        if (!ranks) goto done;
+    } else {
+        ranks = malloc((num_hits ? num_hits : 1) * sizeof(m_docrank_t));
+        memset(ranks, 0, (num_hits ? num_hits : 1) * sizeof(m_docrank_t));   /* malloc garbage in the reference */
+        uint32_t rp = 0;
+        for (size_t w = 0; w < c->W; w++) {                              /* bmap_iterate -> setup_ranks */
+            uint64_t x = docid_map[w];
+            while (x) {
+                int r = __builtin_ctzll(x);
+                x &= x - 1;
+                ranks[rp].docid = (uint32_t)(w * 64 + (size_t)r);
+                perform_doc_rank(c, &ranks[rp]);
+                rp++;
+            }
         }
-    }
-    if (flags & 2) {
-        out->dbg_all_ranks = malloc((num_hits ? num_hits : 1) * sizeof(m_docrank_t));
-        memcpy(out->dbg_all_ranks, ranks, num_hits * sizeof(m_docrank_t));
+        if (flags & 2) {
+            out->dbg_all_ranks = malloc((num_hits ? num_hits : 1) * sizeof(m_docrank_t));
+            memcpy(out->dbg_all_ranks, ranks, num_hits * sizeof(m_docrank_t));
+        }
     }
 
     /* sort_facets (squery.c:411-457) */
@@ -659,6 +777,15 @@ int orc_execute_squery(const mshard_t *s, const m_query_t *q, int shard_idx, int
         int rcount = q->cfg.max_facet_results * 2;
         if ((int)h->population > rcount) orc_facet_partialsort(fc, 0, h->population - 1, (size_t)rcount);
         else rcount = (int)h->population;
+        if (c->fast_rank) {                                          /* get_facet_totalcount, squery.c:398-408,439-446 */
+            for (int x = 0; x < rcount; x++) {
+                const uint32_t *docs;
+                uint64_t n = mshard_facet_posting(s, i, fc[x].facet_id, &docs);
+                uint32_t cnt = 0;
+                for (uint64_t k = 0; k < n; k++) cnt += bm_test(docid_map, docs[k]) ? 1u : 0u;
+                fc[x].count = cnt;
+            }
+        }
         for (int x = 0; x < rcount; x++) fc[x].shard_id = (uint8_t)shard_idx;
         out->fc[i] = fc;
         out->rcount[i] = rcount;
@@ -668,11 +795,11 @@ int orc_execute_squery(const mshard_t *s, const m_query_t *q, int shard_idx, int
     {
         int sortcnt = q->cfg.hits_per_page * q->page_num;
         if (q->cfg.hits_per_page > 0) {
-            if (num_hits >= M_PARTIAL_SORT_LIMIT && num_hits > (uint32_t)sortcnt)
-                orc_rank_partial_sort(ranks, 0, num_hits - 1, (size_t)sortcnt, q->rank_rule);
-            else orc_rank_sort(num_hits, ranks, q->rank_rule);
+            if (resultcount >= M_PARTIAL_SORT_LIMIT && resultcount > (uint32_t)sortcnt)
+                orc_rank_partial_sort(ranks, 0, resultcount - 1, (size_t)sortcnt, q->rank_rule);
+            else orc_rank_sort(resultcount, ranks, q->rank_rule);
         }
-        out->rank_count = ((uint32_t)sortcnt < num_hits) ? sortcnt : (int)num_hits;
+        out->rank_count = ((uint32_t)sortcnt < resultcount) ? sortcnt : (int)resultcount;
         if (!(flags & 4)) orc_rank_sort((size_t)out->rank_count, ranks, q->rank_rule);   /* form_result, query.c:347 */
     }
     out->ranks = ranks;

@@ -55,8 +55,8 @@ def test_posting_ops_match_set_algebra(dg):
 
 def test_unsupported_mode_is_reported_not_approximated(dg):
     ix, eng = dg
-    # fast-rank would apply (not fullScan, more hits than the threshold, rankBy): refused, no fallback
-    pq = ix.query({"q": "", "rankBy": {"id": "asc"}, "fullScanThreshold": 5000})
+    # fast-rank with a cardinality aggregation (the reference dereferences NULL there, metric-aggs.c:23-45): refused, no fallback
+    pq = ix.query({"q": "", "rankBy": {"id": "asc"}, "fullScanThreshold": 5000, "aggs": {"c": {"cardinality": {"field": "facet"}}}})
     with pytest.raises(GpuError) as e:
         eng.search(pq)
     assert "-5" in str(e.value)                                     # MGPU_E_UNSUPPORTED
