@@ -216,6 +216,9 @@ def load():
         "m_slot_pack_batch": (None, [C.POINTER(SqResult), ci, ci, ci, ci, ci, vp]),
         "m_slot_unpack_gathered": (None, [vp, ci, ci, ci, ci, ci, ci, ci, C.POINTER(SqResult)]),
         "m_slot_unpack_gathered_subset": (None, [vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, C.POINTER(SqResult)]),
+        "m_slot_card_count": (C.c_uint64, [C.POINTER(SqResult), ci, ci]),
+        "m_slot_card_pack": (None, [C.POINTER(SqResult), ci, ci, vp]),
+        "m_slot_card_attach": (ci, [vp, vp, C.c_uint64, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, C.POINTER(SqResult)]),
         "m_form_result_batch": (C.c_long, [C.POINTER(C.POINTER(Query)), C.POINTER(SqResult), ci, ci, C.POINTER(Result), ci]),
         "mmirror_gpu": (vp, [vp]),
         "msq_execute_batch": (ci, [vp, C.POINTER(vp), ci, C.POINTER(C.POINTER(Query)), ci, ci, C.POINTER(SqResult)]),

@@ -461,8 +461,9 @@ size_t m_sizeof(int which) {
 
 /* ------------------------------------------------------------------ result slots
  * Fixed-size wire form of one shard's squery_result, for the cross-GPU gather that replaces
- * the shared-memory hand-off of query.c:319-383.  Cardinality id sets are variable-length and
- * are not carried (multi-GPU). */
+ * the shared-memory hand-off of query.c:319-383.  Cardinality id sets are variable-length: a slot carries only their
+ * sizes (m_agg_t.card_n), the ids travel in a second buffer (m_slot_card_*), concatenated in (result, agg) order, and
+ * are attached again after the gather. */
 typedef struct m_slot_hdr {
     uint32_t num_hits; int32_t rank_count; int32_t num_facets; int32_t num_aggs;
     int32_t rcount[M_MAX_FIELDS];
@@ -489,7 +490,7 @@ void m_slot_pack(const m_sqresult_t *r, int k, int num_facets, int fmax, int num
         p += (size_t)fmax * sizeof(m_facet_count_t);
     }
     for (int a = 0; a < num_aggs; a++) {
-        m_agg_t ag = r->aggs[a]; ag.card_ids = NULL; ag.card_n = 0;
+        m_agg_t ag = r->aggs[a]; ag.card_ids = NULL;          /* card_n stays: the ids follow in the card buffer */
         memcpy(p, &ag, sizeof(ag)); p += sizeof(ag);
     }
 }
@@ -510,7 +511,54 @@ void m_slot_unpack(const uint8_t *buf, int k, int num_facets, int fmax, int num_
         for (int x = 0; x < h.rcount[f]; x++) out->fc[f][x].shard_id = (uint8_t)shard_idx;
         p += (size_t)fmax * sizeof(m_facet_count_t);
     }
-    for (int a = 0; a < num_aggs; a++) { memcpy(&out->aggs[a], p, sizeof(m_agg_t)); p += sizeof(m_agg_t); }
+    for (int a = 0; a < num_aggs; a++) {
+        memcpy(&out->aggs[a], p, sizeof(m_agg_t)); p += sizeof(m_agg_t);
+        out->aggs[a].card_ids = NULL; out->aggs[a].card_n = 0;   /* set again by m_slot_card_attach (the slot keeps the size) */
+    }
+}
+
+/* ---- the cardinality side channel: ids of every (result, agg) of a batch, concatenated */
+uint64_t m_slot_card_count(const m_sqresult_t *rs, int n, int num_aggs) {
+    uint64_t t = 0;
+    for (int i = 0; i < n; i++) for (int a = 0; a < num_aggs; a++) if (rs[i].aggs[a].type == MA_CARDINALITY) t += rs[i].aggs[a].card_n;
+    return t;
+}
+void m_slot_card_pack(const m_sqresult_t *rs, int n, int num_aggs, uint32_t *buf) {
+    uint64_t at = 0;
+    for (int i = 0; i < n; i++) for (int a = 0; a < num_aggs; a++) {
+        const m_agg_t *ag = &rs[i].aggs[a];
+        if (ag->type != MA_CARDINALITY || !ag->card_n) continue;
+        memcpy(buf + at, ag->card_ids, (size_t)ag->card_n * sizeof(uint32_t)); at += ag->card_n;
+    }
+}
+/* one rank's gathered slots (nq x local_shards, in pack order) and its card buffer: gives every cardinality agg of
+ * sq[...] its ids back.  The slots are walked in pack order whether or not the caller unpacked them all (q_first /
+ * q_step select the queries that were: m_slot_unpack_gathered_subset; 0 / 1 = all).  Returns 0, or -1 when the buffer
+ * is shorter than the slots say. */
+int m_slot_card_attach(const uint8_t *slots, const uint32_t *card, uint64_t card_n, int rank, int nranks, int nq, int local_shards,
+                       int k, int num_facets, int fmax, int num_aggs, int q_first, int q_step, m_sqresult_t *sq) {
+    size_t sb = m_slot_bytes(k, num_facets, fmax, num_aggs);
+    int total = nranks * local_shards;
+    uint64_t at = 0;
+    for (int q = 0; q < nq; q++)
+        for (int sidx = 0; sidx < local_shards; sidx++) {
+            const uint8_t *p = slots + ((size_t)q * local_shards + sidx) * sb + sizeof(m_slot_hdr_t) +
+                               (size_t)k * sizeof(m_docrank_t) + (size_t)num_facets * (size_t)fmax * sizeof(m_facet_count_t);
+            const int mine = q >= q_first && (q - q_first) % q_step == 0;
+            for (int a = 0; a < num_aggs; a++) {
+                m_agg_t ag; memcpy(&ag, p + (size_t)a * sizeof(m_agg_t), sizeof(ag));
+                if (ag.type != MA_CARDINALITY || !ag.card_n) continue;
+                if (at + ag.card_n > card_n) return -1;
+                if (mine) {
+                    m_sqresult_t *o = &sq[(size_t)((q - q_first) / q_step) * total + (size_t)rank * local_shards + sidx];
+                    o->aggs[a].card_ids = malloc((size_t)ag.card_n * sizeof(uint32_t));
+                    memcpy(o->aggs[a].card_ids, card + at, (size_t)ag.card_n * sizeof(uint32_t));
+                    o->aggs[a].card_n = ag.card_n;
+                }
+                at += ag.card_n;
+            }
+        }
+    return 0;
 }
 
 void m_sqresult_free_batch(m_sqresult_t *rs, int n) { for (int i = 0; i < n; i++) m_sqresult_free(&rs[i]); }

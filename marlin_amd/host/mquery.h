@@ -59,11 +59,16 @@ void m_rank_sort_canonical(m_docrank_t *a, size_t n, const int *rules);
 
 /* Result slots: fixed-size wire form of one shard's squery_result for the cross-GPU gather that
  * replaces the in-process hand-off of query.c:319-383 (k rank records, fmax facet entries per
- * facet field, num_aggs aggregation partials; cardinality id sets are not carried). */
+ * facet field, num_aggs aggregation partials; cardinality id sets travel in a second, variable-length buffer:
+ * m_slot_card_count / _pack on the sending side, m_slot_card_attach per sending rank after the gather). */
 size_t m_slot_bytes(int k, int num_facets, int fmax, int num_aggs);
 void m_slot_pack(const m_sqresult_t *r, int k, int num_facets, int fmax, int num_aggs, uint8_t *buf);
 void m_slot_unpack(const uint8_t *buf, int k, int num_facets, int fmax, int num_aggs, int shard_idx, m_sqresult_t *out);
 void m_slot_pack_batch(const m_sqresult_t *rs, int n, int k, int num_facets, int fmax, int num_aggs, uint8_t *buf);
+uint64_t m_slot_card_count(const m_sqresult_t *rs, int n, int num_aggs);
+void m_slot_card_pack(const m_sqresult_t *rs, int n, int num_aggs, uint32_t *buf);
+int  m_slot_card_attach(const uint8_t *slots, const uint32_t *card, uint64_t card_n, int rank, int nranks, int nq, int local_shards,
+                        int k, int num_facets, int fmax, int num_aggs, int q_first, int q_step, m_sqresult_t *sq);
 /* gathered layout: [rank][query][local shard]; output sq[query * total_shards + shard] */
 void m_slot_unpack_gathered(const uint8_t *buf, int nranks, int nq, int local_shards, int k, int num_facets,
                             int fmax, int num_aggs, m_sqresult_t *sq);

@@ -30,7 +30,7 @@ nq = len(pqs)
 outs = (ffi.SqResult * nq)()
 for i, pq in enumerate(pqs):
     assert orc.orc_execute_squery(ix.shards[rank], pq.q, rank, 0, C.byref(outs[i])) == 0
-g = ShardGather(lib, dist, world, rank, nq, 1, 100, len(ix.facets), 40, 4)
+g = ShardGather(lib, dist, world, rank, nq, 1, 100, len(ix.facets), 40, 4, cardinality=True)
 sq = g.gather(outs)
 if rank == 0:
     qarr = (C.POINTER(ffi.Query) * nq)(*[p.q for p in pqs])
@@ -57,6 +57,8 @@ QUERIES = [
     {"q": "blue", "rankBy": {"price": "desc"}, "hitsPerPage": 15, "aggs": {"s": {"stats": {"field": "price"}}, "m": {"max": {"field": "price"}}}},
     {"q": "", "filter": {"brand": "acme"}, "sortBy": {"price": "asc"}, "hitsPerPage": 30},
     {"q": "grn shirt", "hitsPerPage": 10},
+    {"q": "shoe", "aggs": {"c": {"cardinality": {"field": "size"}}, "b": {"cardinality": {"field": "brand"}}, "a": {"avg": {"field": "price"}}}},
+    {"q": "", "filter": {"size": "s1"}, "aggs": {"c": {"cardinality": {"field": "brand"}}}},
 ]
 
 
@@ -83,7 +85,7 @@ def result_view(res, pq):
             v["facets"][str(f)] = sorted([res.fc[f][x].count, res.fc[f][x].facet_id] for x in range(res.fcount[f]))
     for a in range(res.num_aggs):
         ag = res.aggs[a]
-        v["aggs"].append([ag.type, ag.value, ag.sum, ag.min, ag.max, ag.count])
+        v["aggs"].append([ag.type, ag.value, ag.sum, ag.min, ag.max, ag.count, sorted(ag.card_ids[i] for i in range(ag.card_n))])
     return v
 
 
@@ -108,6 +110,7 @@ def test_two_rank_gather_equals_single_process_merge(tmp_path):
         for s in range(2):
             lib.m_sqresult_free(C.byref(outs[s]))
     assert expect[0]["total"] > 0 and expect[1]["aggs"]
+    assert len(expect[4]["aggs"][0][6]) == 6 and len(expect[4]["aggs"][1][6]) == 3      # cardinality: distinct ids across both shards
 
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
