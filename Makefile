@@ -30,7 +30,7 @@ marlin_amd/lib/libmarlin_host.so: $(HOST_SRC) $(HOST_HDR) marlin_amd/lib/libmarl
 
 oracle/liborc.so: $(ORC_SRC) oracle/orc.h $(HOST_HDR) marlin_amd/lib/libmarlin_host.so
 	$(CC) $(CFLAGS) -shared -o $@ $(ORC_SRC) -Lmarlin_amd/lib -lmarlin_host \
-	    -Wl,-rpath,'$$ORIGIN/../marlin_amd/lib' -lm
+	    -Wl,-rpath,'$$ORIGIN/../marlin_amd/lib' -lm -lpthread
 
 # The reference's own bitmap / sort / hashtable / farmhash sources, compiled unmodified from
 # where they lie.  Only possible where /root/reference exists (the build container).

@@ -4,8 +4,9 @@
 Workload (BASELINE.json `metric` / configs[2]): a 10M-document synthetic Zipf index in 8 shards,
 a stream of 3-term queries (two typo'd frequent words + a 3-letter prefix, i.e. 6 terms with
 typo / prefix expansion), facets on 2 fields (64 and 100k buckets), rankBy a unique numeric
-field, top-10, fullScan.  A "step" is one batch of queries taken through execute_squery on every
-shard (plan lowering + GPU launches) and the form_result merge.
+field, top-10, fullScan.  A "step" is one batch of --batch x --sub queries (default 128 x 64 = 8192) taken through
+execute_squery on every shard (plan lowering + GPU launches) and the form_result merge; the device takes it as --sub
+launches of --batch queries each, --inflight of them in flight.
 
   N = 1 : all 8 shards on one GPU.
   N > 1 : shards split over the ranks (8/N each; the corpus is fixed but the queries per step grow with N, so a rank's work per step is constant => weak scaling); every rank runs
@@ -14,7 +15,8 @@ shard (plan lowering + GPU launches) and the form_result merge.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant
 kernel stage (HIP-event timed on the launch stream) and `cpu_baseline` (the C oracle = port of the
-reference's CPU path, 1 core, bounded sample).
+reference's CPU path run as the reference runs it: a thread pool over (query, shard) jobs on the host's cores,
+bounded sample).
 """
 import argparse
 import ctypes as C
@@ -73,12 +75,14 @@ def make_queries(lib, n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=24)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--docs", type=int, default=10_000_000)
-    ap.add_argument("--batch", type=int, default=128, help="queries per step and GPU")
-    ap.add_argument("--cpu-queries", type=int, default=256,
-                    help="bench queries the one-core CPU baseline runs (about 13 s of CPU work at the default)")
+    ap.add_argument("--batch", type=int, default=128, help="queries per device launch sequence (sub-batch) and GPU")
+    ap.add_argument("--sub", type=int, default=64, help="sub-batches per step: a step is --batch x --sub queries per GPU")
+    ap.add_argument("--cpu-queries", type=int, default=512,
+                    help="bench queries the CPU baseline runs (about 25 s of CPU work at the default, spread over the cores)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = the cores this process may use, at most 16)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="multi-rank rehearsal on ONE GPU: gloo collectives on host tensors, every rank on cuda:0")
@@ -126,7 +130,8 @@ def main():
     # queries per step grow with the number of GPUs so that a rank's batch (queries x its shards)
     # keeps the same size: the corpus is fixed, the query stream is not: per-GPU work per step is constant (weak scaling)
     B = args.batch * world
-    nq_pool = max(256, 2 * B)
+    S = max(1, args.sub)
+    nq_pool = max(256, 2 * B)            # (the same 256 queries as round 1: the mean hit count of a sample moves the rate)
     pool = [ix.query(j) for j in make_queries(lib, nq_pool)]
     K_TOP, NF, FMAX, NAGG = 10, 2, 20, 0
     slot_b = lib.m_slot_bytes(K_TOP, NF, FMAX, NAGG)
@@ -237,10 +242,10 @@ def main():
     t_warm = time.time() - t0
     barrier()
 
-    run_steps(0, args.warmup)
+    run_steps(0, args.warmup * S)
     barrier()
     t0 = time.perf_counter()
-    total_hits = run_steps(args.warmup, args.steps)
+    total_hits = run_steps(args.warmup * S, args.steps * S)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -251,7 +256,7 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearse_gloo else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    qps = args.steps * B / dt
+    qps = args.steps * S * B / dt
 
     # ---- single-query latency (batch of 1, unloaded), p50 / p99 over 200 queries
     lat, lat_full = [], []
@@ -294,16 +299,16 @@ def main():
         ms, by = acc[k][0] / nprof, acc[k][1] / nprof
         stage_tab[k] = {"ms": round(ms, 4), "MB": round(by / 1e6, 3), "GBps": round(by / ms / 1e6, 1) if ms > 0 else None}
     ach = acc[dom][1] / acc[dom][0] / 1e6          # bytes / ms -> GB/s
-    KERNELS = {"rank": "k_rank_tile + k_rank_overflow", "select": "k_select_first + k_select_mid (+ k_select_items, k_select_final)", "formula+compact": "k_formula + k_scan + k_compact",
-               "facets+aggs": "k_docproc + k_aggfinal", "facet-keys": "k_fkeys + k_card", "scatter": "k_scatter"}
+    KERNELS = {"rank": "k_rank_tile + k_rank_overflow", "select": "k_select_first + k_select_mid (+ k_select_items, k_select_final)", "formula+compact": "k_formula + k_order + k_order_copy",
+               "facets+aggs": "k_docproc + k_aggfinal", "facet-keys": "k_fkeys + k_card + k_facet_hash", "scatter": "k_scatter_list"}
     # HBM traffic of the dominant kernel comes from separate PMC passes (rocprofv3 cannot run inside the
-    # timed program): profiles/r01_pmc_fetch_write_per_launch.json, same command and batch size
+    # timed program): profiles/r02_pmc_fetch_write_per_launch.json, same batch size and queries
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_per_launch.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_fetch_write_per_launch.json")) as f:
             pm = json.load(f)
         if dom == "rank" and B == 128 and world == 1 and args.docs == 10_000_000:
-            traffic = pm["k_rank_tile_hbm_bytes_per_launch"]
+            traffic = pm["kernels"]["k_rank_tile"]["hbm_bytes_per_launch"] + pm["kernels"]["k_rank_overflow"]["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
     roof = {"bound": "hbm", "kernel": KERNELS.get(dom, dom), "stage": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -316,20 +321,30 @@ def main():
         from oracle import orc_py
         orc_py.load()
         n = max(1, min(args.cpu_queries, len(pool)))
-        orc_py.lookup_time(True)
-        t1 = time.perf_counter()
-        chk = 0
-        for i in range(n):
-            outs = orc_py.execute_raw(ix, pool[i])
-            chk += sum(outs[s].num_hits for s in range(local))
-            for s in range(local):
-                lib.m_sqresult_free(C.byref(outs[s]))
-        cdt = time.perf_counter() - t1
-        tl = orc_py.lookup_time(True)
-        cpu = {"value": round(n / max(1e-9, cdt - tl), 3), "unit": "queries/s", "cores": 1, "kind": "port",
-               "sample": "%d of the bench queries, all 8 shards sequentially, oracle/orc_squery.c; dictionary "
-                         "lookup time excluded as on the GPU side" % n,
-               "with_term_lookup": round(n / cdt, 3), "total_hits": chk}
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        nthr = args.cpu_threads if args.cpu_threads > 0 else max(1, min(16, avail))
+        model = "unknown"
+        try:
+            with open("/proc/cpuinfo") as f:
+                for ln in f:
+                    if ln.startswith("model name"):
+                        model = ln.split(":", 1)[1].strip()
+                        break
+        except OSError:
+            pass
+        # the reference's shape: search_pool runs one execute_squery job per (query, shard) (query.c:435-452)
+        wall, lk, busy, chk = orc_py.bench_pool(ix, pool[:n], nthr)
+        frac = lk / max(1e-9, busy)                 # share of the workers' time spent in dictionary lookups
+        cpu = {"value": round(n / max(1e-9, wall * (1.0 - frac)), 3), "unit": "queries/s", "cores": nthr, "kind": "port",
+               "sample": "%d of the bench queries x 8 shards = %d execute_squery jobs over a pool of %d threads, "
+                         "oracle/orc_squery.c; dictionary lookup time (%.1f%% of worker time) excluded as on the GPU side"
+                         % (n, n * local, nthr, 100 * frac),
+               "with_term_lookup": round(n / wall, 3), "one_core_equivalent": round(n / max(1e-9, busy - lk), 3),
+               "cpu_seconds": round(busy, 2), "host_cpu": model, "host_cores_visible": os.cpu_count(), "host_cores_usable": avail,
+               "total_hits": chk}
 
     if rank == 0:
         line = {
@@ -339,8 +354,8 @@ def main():
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "configs[2]: %d docs Zipf corpus, %d shards, 3-word typo+prefix query, 2 facet fields, "
                                    "rankBy num desc, top-10, fullScan" % (args.docs, TOTAL_SHARDS),
-                       "queries_per_step": B, "batches_in_flight": F, "shards_per_gpu": local, "vocab": VOCAB,
-                       "mean_hits_per_query": round(total_hits / max(1, args.steps * B), 1)},
+                       "queries_per_step": B * S, "queries_per_device_batch": B, "device_batches_per_step": S, "batches_in_flight": F, "shards_per_gpu": local, "vocab": VOCAB,
+                       "mean_hits_per_query": round(total_hits / max(1, args.steps * S * B), 1)},
             "roofline": roof, "cpu_baseline": cpu,
             "latency_ms": {"p50": round(lat[len(lat) // 2], 3), "p99": round(lat[int(len(lat) * 0.99)], 3),
                            "with_term_lookup_p50": round(lat_full[len(lat_full) // 2], 3),

@@ -14,8 +14,9 @@
  * Differences from the reference, on purpose:
  *   - bitmaps are dense u64 words, not roaring containers (same sets; validated against
  *     oracle/_ref bmap.c);
- *   - fast-rank mode (docrank.c:478-560) is not restated: callers must use fullScan or stay
- *     under fullScanThreshold (orc_execute_squery returns -2 otherwise).
+ *   - fast-rank mode (docrank.c:478-560) is restated as the reference runs it; where the reference itself
+ *     misbehaves (a cardinality aggregation: NULL dereference; a sample larger than its rank buffer)
+ *     orc_execute_squery returns -5 / -3 instead.
  */
 #ifndef MARLIN_ORACLE_ORC_H
 #define MARLIN_ORACLE_ORC_H
@@ -56,8 +57,15 @@ void     orc_bm_andnot(uint64_t *dst, const uint64_t *src, size_t words);
 uint64_t orc_bm_cardinality(const uint64_t *a, size_t words);
 void     orc_bm_from_list(uint64_t *dst, const uint32_t *docs, uint64_t n);
 
-/* seconds spent inside mdict_lookup_term / mdict_lookup_exact since the last reset (not thread safe) */
+/* seconds this thread spent inside mdict_lookup_term / mdict_lookup_exact since its last reset */
 double orc_lookup_time(int reset);
+
+/* cpu_baseline at more than one core: the reference's search_pool shape (query.c:435-452, marlin.c:38-44: one
+ * execute_squery job per (query, shard), a pool of threads).  nthreads workers take the nq x nshards jobs from a
+ * shared counter.  Returns wall seconds; *lookup_cpu_s / *busy_cpu_s = seconds summed over the workers spent in
+ * dictionary lookups / in execute_squery as a whole; *hits = sum of num_hits (a checksum). */
+double orc_bench_pool(const mshard_t *const *shards, int nshards, const m_query_t *const *queries, int nq, int nthreads,
+                      double *lookup_cpu_s, double *busy_cpu_s, uint64_t *hits);
 
 #ifdef __cplusplus
 }

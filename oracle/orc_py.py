@@ -25,6 +25,9 @@ def load():
         lib.orc_execute_squery.argtypes = [C.c_void_p, C.POINTER(ffi.Query), C.c_int, C.c_int, C.POINTER(ffi.SqResult)]
         lib.orc_lookup_time.restype = C.c_double
         lib.orc_lookup_time.argtypes = [C.c_int]
+        lib.orc_bench_pool.restype = C.c_double
+        lib.orc_bench_pool.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.POINTER(ffi.Query)), C.c_int, C.c_int,
+                                       C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
         _lib = lib
     return _lib
 
@@ -53,3 +56,14 @@ def search(index, pq, flags=0):
     for s in range(index.num_shards):
         index.lib.m_sqresult_free(C.byref(outs[s]))
     return r
+
+
+def bench_pool(index, pqs, nthreads):
+    """the oracle over a thread pool, one job per (query, shard) like the reference's search_pool (query.c:435-452).
+    Returns (wall seconds, lookup cpu seconds, busy cpu seconds, total hits)."""
+    lib = load()
+    sh = (C.c_void_p * index.num_shards)(*[s.value for s in index.shards])
+    qs = (C.POINTER(ffi.Query) * len(pqs))(*[p.q for p in pqs])
+    lk, busy, hits = C.c_double(), C.c_double(), C.c_uint64()
+    wall = lib.orc_bench_pool(sh, index.num_shards, qs, len(pqs), nthreads, C.byref(lk), C.byref(busy), C.byref(hits))
+    return wall, lk.value, busy.value, hits.value

@@ -9,7 +9,7 @@
 
 /* seconds spent in the dictionary (trie) lookups since the last reset: lets bench.py report the
  * CPU baseline with and without the term lookup, which the GPU path keeps on the host too */
-double orc_lookup_seconds = 0.0;
+static __thread double orc_lookup_seconds = 0.0;
 static double orc_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
 double orc_lookup_time(int reset) { double v = orc_lookup_seconds; if (reset) orc_lookup_seconds = 0.0; return v; }
 
@@ -826,4 +826,58 @@ done:
     m_u32map_free(&c->all_wordids);
     free(c);
     return rc;
+}
+
+/* ------------------------------------------------------------------ cpu_baseline on several cores */
+#include <pthread.h>
+#include <malloc.h>
+typedef struct {
+    const mshard_t *const *shards; int nshards; const m_query_t *const *queries; int nq;
+    int *next; pthread_mutex_t *mu;
+    double lookup_s, busy_s; uint64_t hits;
+} pool_job_t;
+
+static void *pool_worker(void *arg) {
+    pool_job_t *j = arg;
+    orc_lookup_time(1);
+    const int total = j->nq * j->nshards;
+    for (;;) {
+        pthread_mutex_lock(j->mu);
+        const int i = (*j->next)++;
+        pthread_mutex_unlock(j->mu);
+        if (i >= total) break;
+        m_sqresult_t out;
+        const double t0 = orc_now();
+        orc_execute_squery(j->shards[i % j->nshards], j->queries[i / j->nshards], i % j->nshards, 0, &out);
+        j->busy_s += orc_now() - t0;
+        j->hits += out.num_hits;
+        m_sqresult_free(&out);
+    }
+    j->lookup_s = orc_lookup_time(1);
+    return NULL;
+}
+
+double orc_bench_pool(const mshard_t *const *shards, int nshards, const m_query_t *const *queries, int nq, int nthreads,
+                      double *lookup_cpu_s, double *busy_cpu_s, uint64_t *hits) {
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 256) nthreads = 256;
+    /* per-query maps of a few MB: keep them in the threads' arenas instead of mmap/munmap per job (page faults
+     * under one mm lock serialise the pool) */
+    mallopt(M_MMAP_THRESHOLD, 32 << 20);          /* glibc's maximum */
+    mallopt(M_TRIM_THRESHOLD, 1 << 30);
+    mallopt(M_TOP_PAD, 64 << 20);
+    pool_job_t jobs[256]; pthread_t th[256];
+    int next = 0; pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+    const double t0 = orc_now();
+    for (int t = 0; t < nthreads; t++) {
+        jobs[t] = (pool_job_t){ shards, nshards, queries, nq, &next, &mu, 0.0, 0.0, 0 };
+        pthread_create(&th[t], NULL, pool_worker, &jobs[t]);
+    }
+    double lk = 0, busy = 0; uint64_t h = 0;
+    for (int t = 0; t < nthreads; t++) { pthread_join(th[t], NULL); lk += jobs[t].lookup_s; busy += jobs[t].busy_s; h += jobs[t].hits; }
+    const double wall = orc_now() - t0;
+    if (lookup_cpu_s) *lookup_cpu_s = lk;
+    if (busy_cpu_s) *busy_cpu_s = busy;
+    if (hits) *hits = h;
+    return wall;
 }

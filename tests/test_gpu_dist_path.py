@@ -38,7 +38,7 @@ lib.m_form_result_batch(qarr, outs, nq, 2, res, 1)
 direct = [result_view(res[i], pqs[i]) for i in range(nq)]
 eng.free_raw(outs)
 # through the gather, twice in a row from two worker threads (slot reuse, per-thread device state)
-g = ShardGather(lib, dist, 1, 0, nq, 2, 100, len(ix.facets), 40, 4, device="cuda:0", nslots=2)
+g = ShardGather(lib, dist, 1, 0, nq, 2, 100, len(ix.facets), 40, 4, device="cuda:0", nslots=2, cardinality=True)
 got = {}
 lock = threading.Lock()
 def work(t):

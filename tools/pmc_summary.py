@@ -22,7 +22,7 @@ def main():
     f, w, o = sys.argv[1:4]
     fe, wr = per_kernel(f, "FETCH_SIZE"), per_kernel(w, "WRITE_SIZE")
     doc = {"_about": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `python3 bench.py --no-cpu "
-                     "--no-latency --inflight 1 --steps 3 --warmup 1`; KB per launch, averaged over the batched launches "
+                     "--no-latency --inflight 1 --steps 1 --warmup 0 --sub 3`; KB per launch, averaged over the batched launches "
                      "(1024 squeries). HBM bytes = 2 x FETCH_SIZE (gfx950 counts 128-B requests at 64 B, MI355X_MICROARCH.md) "
                      "+ WRITE_SIZE.",
            "kernels": {k: {"FETCH_SIZE_KB_avg": fe.get(k, 0.0), "WRITE_SIZE_KB_avg": wr.get(k, 0.0)} for k in sorted(set(fe) | set(wr))}}
