@@ -28,6 +28,7 @@ __device__ __forceinline__ bool key_lt(u64 ah, u64 al, uint32_t ai, u64 bh, u64 
 }
 // ---- optional phase clocks (mgpu_debug_phases): cycles summed per phase over the active workgroups
 __device__ int mg_dbg_on = 0;
+__device__ int mg_dbg_skip = 0;        // diagnostic: bit 2 = k_rank_tile without phase 2, bit 4 = without probing (tools/rank_parts.py); keys are then wrong, nothing else is
 __device__ unsigned long long mg_dbg_acc[32];
 #define DBG_T(var) const long long var = mg_dbg_on ? (long long)wall_clock64() : 0
 #define DBG_ADD(slot, a, b) do { if (mg_dbg_on && threadIdx.x == 0) atomicAdd(&mg_dbg_acc[slot], (unsigned long long)((b) - (a))); } while (0)
@@ -831,6 +832,7 @@ __global__ __launch_bounds__(MG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
     __shared__ uint2 s_match[MG_BLOCK * MG_MCAP];
     __shared__ uint32_t s_pairs[MG_BLOCK * MG_PCAP];
     const uint32_t ntiles = *tile_count;
+    const int skip = mg_dbg_skip;
     const uint32_t tid = threadIdx.x;
     const uint32_t grp = tid >> 4, gl = tid & 15;
     // a workgroup takes a run of consecutive tiles: a squery's tiles sit together on the list, so its wid table is
@@ -886,9 +888,13 @@ __global__ __launch_bounds__(MG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
             // two explicit probe paths: through a runtime-selected pointer the compiler would emit
             // flat loads (LDS or global decided per access) and wait on each one
             const bool tab_in_lds = do_rank && hmask < MG_LDS_HASH;
+            const uint32_t gshift = tid & 48u;                     // the group's first bit in a wave ballot
+            const uint32_t gbelow = (1u << gl) - 1u;               // the group's lanes below this one
+            // match records are r-major (record r of document d at [r * MG_BLOCK + d]): phase 2 reads its document's
+            // records lane-strided, without bank conflicts
             auto record = [&](uint32_t d, uint32_t val, uint32_t info) {
                 const uint32_t r = atomicAdd(&s_cnt[d], 1u);
-                if (r < MG_MCAP) s_match[d * MG_MCAP + r] = make_uint2(val, info);
+                if (r < MG_MCAP) s_match[r * MG_BLOCK + d] = make_uint2(val, info);
             };
             auto take = [&](uint32_t d, uint32_t wid, uint32_t info) {          // full probe (tails, global tables)
                 uint32_t val;
@@ -941,7 +947,7 @@ __global__ __launch_bounds__(MG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                     if (s0 + 1 >= ws && s0 + 1 < ws + nin) in_b |= 1u << k;
                     if (nin + ws > 32 || (h0 & 0xFFFFu) > nin) tail |= 1u << k;
                 }
-                if (do_rank) {
+                if (do_rank && !(skip & 4)) {
                     if (tab_in_lds) {
                         // first probes of all sixteen entries issued together; the table is sparse, so they
                         // settle nearly every word (empty slot = not a query word)
@@ -957,14 +963,21 @@ __global__ __launch_bounds__(MG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                             for (int k = 0; k < 4; k++) {
                                 const uint32_t d = grp * 16 + half * 8 + q4 + k;
                                 const uint4 e = v[q4 + k];
-                                if ((in_a >> (q4 + k)) & 1u) {
-                                    if (pa[k].x == e.x) record(d, pa[k].y, e.y);
-                                    else if (pa[k].x != 0) take_from(d, e.x, e.y, hash_wid(e.x) & hmask);
-                                }
-                                if ((in_b >> (q4 + k)) & 1u) {
-                                    if (pb[k].x == e.z) record(d, pb[k].y, e.w);
-                                    else if (pb[k].x != 0) take_from(d, e.z, e.w, hash_wid(e.z) & hmask);
-                                }
+                                // The sixteen lanes of the group hold the document's 32 entries: the record slot of
+                                // a match is its rank among the group's matches (two ballots), no LDS atomic and no
+                                // wait for one.  The document belongs to this group alone, so the plain store of its
+                                // count precedes (wave program order) the atomics of the rare paths below.
+                                const bool use_a = (in_a >> (q4 + k)) & 1u, use_b = (in_b >> (q4 + k)) & 1u;
+                                const bool ma = use_a && pa[k].x == e.x, mb = use_b && pb[k].x == e.z;
+                                const uint32_t ga = (uint32_t)(__ballot(ma) >> gshift) & 0xFFFFu;
+                                const uint32_t gb = (uint32_t)(__ballot(mb) >> gshift) & 0xFFFFu;
+                                const uint32_t ra = (uint32_t)__popc(ga & gbelow) + (uint32_t)__popc(gb & gbelow);
+                                const uint32_t rb2 = ra + (ma ? 1u : 0u);
+                                if (ma && ra < MG_MCAP) s_match[ra * MG_BLOCK + d] = make_uint2(pa[k].y, e.y);
+                                if (mb && rb2 < MG_MCAP) s_match[rb2 * MG_BLOCK + d] = make_uint2(pb[k].y, e.w);
+                                if (gl == 0) s_cnt[d] = (uint32_t)__popc(ga) + (uint32_t)__popc(gb);
+                                if (use_a && !ma && pa[k].x != 0) take_from(d, e.x, e.y, hash_wid(e.x) & hmask);
+                                if (use_b && !mb && pb[k].x != 0) take_from(d, e.z, e.w, hash_wid(e.z) & hmask);
                             }
                         }
                     } else {
@@ -1024,40 +1037,6 @@ __global__ __launch_bounds__(MG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                             atomicAdd(&sp->hist[f][code], 1u);
                     }
                 }
-                s_np[tid] = 0;
-                __syncthreads();
-            }
-            // Phase 1b, one lane per match record: fetch the word's positions (the only dependent
-            // global read of the ranking, issued for all records of the tile at once), turn them into
-            // (slot, position) pairs in the document's LDS slice and leave {val, first position}
-            // behind, so that phase 2 never leaves LDS.
-            if (do_rank) {
-                for (uint32_t sl = tid; sl < MG_BLOCK * MG_MCAP; sl += MG_BLOCK) {
-                    const uint32_t d = sl / MG_MCAP, r = sl % MG_MCAP;
-                    if (r >= s_cnt[d]) continue;
-                    const uint2 m = s_match[sl];
-                    if ((m.x & 0xFF) == 0xFF) continue;                 // exact-only entry: no positions needed
-                    const uint32_t info = m.y;
-                    const bool inl = info & 1u;
-                    const uint32_t cnt = inl ? 1u : ((info >> 1) & 0xFFu);
-                    const uint32_t *pd = pp + s_pbase[d] + (info >> 9);
-                    const uint32_t first = inl ? info_first_inline(info) : pd[0];
-                    s_match[sl].y = first;
-                    if (nw == 1) continue;
-                    int slot_a, slot_b; bool keep_a;
-                    rank_slots(nw, nt, (m.x >> 8) & 0xFF, slot_a, slot_b, keep_a);
-                    const uint32_t per = (keep_a ? 1u : 0u) + (slot_b >= 0 ? 1u : 0u);
-                    if (!per) continue;
-                    const uint32_t at = atomicAdd(&s_np[d], per * cnt);
-                    if (at + per * cnt > MG_PCAP) continue;             // phase 2 sees s_np > MG_PCAP: overflow path
-                    uint32_t o = at;
-                    for (uint32_t j = 0; j < cnt; j++) {
-                        const uint32_t p = (j == 0) ? first : pd[j];
-                        if (keep_a) s_pairs[(o++) * MG_BLOCK + d] = ((uint32_t)slot_a << 24) | p;
-                        if (slot_b >= 0) s_pairs[(o++) * MG_BLOCK + d] = ((uint32_t)slot_b << 24) | p;
-                    }
-                }
-                __syncthreads();
             }
         }
         DBG_T(t3); DBG_ADD(16, t0, t3);
@@ -1065,18 +1044,57 @@ __global__ __launch_bounds__(MG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
         if (valid) {
             RankOut ro = {0, 0, 0, 0, 0};
             bool ok = true;
-            if (do_rank) {
+            if (do_rank && !(skip & 2)) {
+                // Phase 2, one lane per document, all in the lane's own LDS columns (no barrier since phase 1's):
+                // the word positions -- the only dependent global reads of the ranking -- are fetched for all of the
+                // document's records in one batch of independent loads (first three positions of every word), then the
+                // records are reduced and their (slot, position) pairs laid down, sorted and walked.
                 const uint32_t cnt = s_cnt[tid];
                 if (cnt > MG_MCAP) ok = false;
                 else {
+                    const uint32_t *pdoc = pp + s_pbase[tid];
+                    uint32_t p0[MG_MCAP], p1[MG_MCAP], p2[MG_MCAP];
+#pragma unroll
+                    for (int r = 0; r < MG_MCAP; r++) {
+                        p0[r] = 0; p1[r] = 0; p2[r] = 0;
+                        if ((uint32_t)r < cnt) {
+                            const uint2 m = s_match[r * MG_BLOCK + tid];
+                            const uint32_t info = m.y;
+                            if ((m.x & 0xFF) != 0xFF) {                       // exact-only entries need no positions
+                                if (info & 1u) p0[r] = info_first_inline(info);
+                                else {
+                                    const uint32_t pc = (info >> 1) & 0xFFu;
+                                    const uint32_t *pd = pdoc + (info >> 9);
+                                    if (pc > 0) p0[r] = pd[0];
+                                    if (nw > 1 && pc > 1) p1[r] = pd[1];
+                                    if (nw > 1 && pc > 2) p2[r] = pd[2];
+                                }
+                            }
+                        }
+                    }
                     RankState st; rank_init(st);
                     LdsPairs ps = {&s_pairs[tid], MG_PCAP};
-                    for (uint32_t r = 0; r < cnt; r++) {
-                        const uint2 m = s_match[tid * MG_MCAP + r];
-                        rank_reduce(st, nw, nt, m.x, m.y);
+#pragma unroll
+                    for (int r = 0; r < MG_MCAP; r++) {
+                        if ((uint32_t)r >= cnt) continue;
+                        const uint2 m = s_match[r * MG_BLOCK + tid];
+                        rank_reduce(st, nw, nt, m.x, p0[r]);
+                        if ((m.x & 0xFF) == 0xFF || nw == 1) continue;
+                        const uint32_t info = m.y;
+                        const uint32_t pc = (info & 1u) ? 1u : ((info >> 1) & 0xFFu);
+                        int slot_a, slot_b; bool keep_a;
+                        rank_slots(nw, nt, (m.x >> 8) & 0xFF, slot_a, slot_b, keep_a);
+                        const uint32_t per = (keep_a ? 1u : 0u) + (slot_b >= 0 ? 1u : 0u);
+                        if (!per) continue;
+                        if ((uint32_t)st.np + per * pc > MG_PCAP) { st.ovf = true; continue; }
+                        const uint32_t *pd = pdoc + (info >> 9);
+                        for (uint32_t j = 0; j < pc; j++) {
+                            const uint32_t pv = (j == 0) ? p0[r] : (j == 1) ? p1[r] : (j == 2) ? p2[r] : pd[j];
+                            if (keep_a) ps.set(st.np++, ((uint32_t)slot_a << 24) | pv);
+                            if (slot_b >= 0) ps.set(st.np++, ((uint32_t)slot_b << 24) | pv);
+                        }
                     }
-                    st.np = (int)s_np[tid];
-                    if (st.np > MG_PCAP) ok = false; else rank_finish(st, nw, exact_present, ps, ro);
+                    if (st.ovf) ok = false; else rank_finish(st, nw, exact_present, ps, ro);
                 }
                 if (!ok) p_ovf_list[atomicAdd(p_ovf_cnt, 1u)] = t;
             }
@@ -2337,6 +2355,7 @@ int mgk_debug_clock_cal(unsigned long long *out3) {
     (void)hipFree(d); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return ok ? 0 : -1;
 }
+int mgk_debug_skip(int mask) { return hipMemcpyToSymbol(HIP_SYMBOL(mg_dbg_skip), &mask, sizeof(int)) == hipSuccess ? 0 : -1; }
 // phase clocks: enable, and read + reset the 16 accumulators (100 MHz wall_clock64 ticks)
 int mgk_debug_phases(int on, unsigned long long *out16) {
     unsigned long long z[32] = {0};
