@@ -946,7 +946,7 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
             for (uint32_t j = 0; j < p.num_wids; j++) {
                 const mgpu_wid_entry_t &e = p.wids[j];
                 if (e.wid == 0) return fail(MGPU_E_ARG, "wid 0 in wid table");
-                uint32_t hsh = e.wid; hsh ^= hsh >> 16; hsh *= 0x7feb352dU; hsh ^= hsh >> 15; hsh *= 0x846ca68bU; hsh ^= hsh >> 16;
+                uint32_t hsh = (uint32_t)((uint64_t)(e.wid & 0xFFFFFFu) * MG_WID_HASH_K); hsh ^= hsh >> 15;      // = hash_wid of the kernels
                 uint32_t slot = hsh & (cap - 1);
                 while (blob[base + slot * 2] != 0 && blob[base + slot * 2] != e.wid) slot = (slot + 1) & (cap - 1);
                 blob[base + slot * 2] = e.wid;

@@ -18,6 +18,7 @@
 #define MG_SEL_FINAL    2048         // candidates sorted by the final block
 #define MG_SCATTER_CHUNK 2048        // docids per scatter work item
 #define MG_LDS_HASH     4096         // wid table slots staged in LDS (32 KiB)
+#define MG_WID_HASH_K   0x9E3779u    // wid table hash: low 32 bits of (wid & 0xFFFFFF) * K, folded with >> 15
 #define MG_LDS_HIST     8192         // facet bins privatised in LDS (32 KiB)
 
 // Device view of one shard mirror.
