@@ -259,7 +259,7 @@ def main():
     qps = args.steps * S * B / dt
 
     # ---- single-query latency (batch of 1, unloaded), p50 / p99 over 200 queries
-    lat, lat_full = [], []
+    lat, lat_full, lat_dev = [], [], []
     if world == 1 and not args.no_latency:
         for i in range(200):
             pq = pool[i % nq_pool]
@@ -275,6 +275,18 @@ def main():
             eng.free_raw(o)
             eng.free_prepared(pr)
         lat.sort(); lat_full.sort()
+        # the same with the typo walks of the term lookup on the device (row f-1)
+        for i in range(200):
+            pq = pool[i % nq_pool]
+            qa = (C.POINTER(ffi.Query) * 1)(pq.q)
+            t0l = time.perf_counter()
+            pr = eng.prepare([pq], device_lookup=True)
+            o = eng.execute_prepared(pr)
+            lib.m_form_result_batch(qa, o, 1, local, None, 0)
+            lat_dev.append((time.perf_counter() - t0l) * 1e3)
+            eng.free_raw(o)
+            eng.free_prepared(pr)
+        lat_dev.sort()
 
     # ---- roofline of the dominant kernel stage: HIP events on the launch stream, profiled batches
     roof = None
@@ -359,7 +371,9 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
             "latency_ms": {"p50": round(lat[len(lat) // 2], 3), "p99": round(lat[int(len(lat) * 0.99)], 3),
                            "with_term_lookup_p50": round(lat_full[len(lat_full) // 2], 3),
-                           "with_term_lookup_p99": round(lat_full[int(len(lat_full) * 0.99)], 3)} if lat else None,
+                           "with_term_lookup_p99": round(lat_full[int(len(lat_full) * 0.99)], 3),
+                           "with_device_term_lookup_p50": round(lat_dev[len(lat_dev) // 2], 3),
+                           "with_device_term_lookup_p99": round(lat_dev[int(len(lat_dev) * 0.99)], 3)} if lat else None,
             "stages": stage_tab,
             "host_ms_per_step": {k: round(v, 3) for k, v in host_acc.items()},
             "setup_s": {"build_shards": round(t_build, 1), "mirror": round(t_mirror, 1), "term_lookup": round(t_prepare, 2),

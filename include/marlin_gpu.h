@@ -239,6 +239,36 @@ int mgpu_posting_op(mgpu_ctx_t *c, mgpu_shard_t *s, int op, uint32_t pid_a, uint
 int mgpu_posting_op_noalloc(mgpu_ctx_t *c, mgpu_shard_t *s, int op, uint32_t pid_a, uint32_t pid_b,
                             uint64_t *out_words, uint32_t nwords, uint64_t *card);
 
+/* ------------------------------------------------------------------ f-1: term lookup on the device
+ * Replaces the typo walk of dtrie_lookup_term (lookup_typo / node_lev, /root/reference/src/main/dtrie.c:710-791, reached
+ * from dtrie.c:805-823 when the term allows typos and is not a short prefix): for every (term, dictionary) pair the
+ * words within the term's edit distance and their least distances (add_wordid_to_result, dtrie.c:633-640; a prefix
+ * term gives a matching node's distance to every word below it, node_walk dtrie.c:642-658).  The device holds the
+ * dictionary as a flat word list, not a trie: every word is scored on its own with the walk's row arithmetic
+ * (marlin_amd/csrc/mg_lev.h), one lane per word.  The twid and no-typo modes (dtrie.c:664-700) are exact descents and
+ * stay with the caller.
+ *
+ * mgpu_dict_create: chars[word_off[i] .. word_off[i+1]) = the code points of the word whose id is word_wid[i];
+ * word_off has num_words + 1 ascending entries.  Words longer than MGPU_MAX_TERM_LEN + 2 cannot match any term.
+ * mgpu_lookup_terms: n lookups in one launch; *hits receives a malloc'd array of {lookup index, wid, distance} in no
+ * particular order (every (lookup, wid) at most once), freed with mgpu_term_hits_free.  Terms of 0 or more than
+ * MGPU_MAX_TERM_LEN characters are refused with MGPU_E_ARG. */
+#define MGPU_MAX_TERM_LEN 127
+typedef struct mgpu_dict mgpu_dict_t;
+typedef struct mgpu_term_lookup {
+    const mgpu_dict_t *dict;
+    const uint32_t *chars;       /* the term's code points */
+    int32_t len;
+    int32_t prefix;              /* term_t.prefix: the last query word, matched as a prefix */
+} mgpu_term_lookup_t;
+typedef struct mgpu_term_hit { uint32_t lookup, wid, dist; } mgpu_term_hit_t;
+int  mgpu_dict_create(int device, const uint32_t *chars, const uint32_t *word_off, const uint32_t *word_wid,
+                      uint32_t num_words, mgpu_dict_t **out);
+void mgpu_dict_destroy(mgpu_dict_t *d);
+uint64_t mgpu_dict_bytes(const mgpu_dict_t *d);
+int  mgpu_lookup_terms(mgpu_ctx_t *c, const mgpu_term_lookup_t *lookups, int n, mgpu_term_hit_t **hits, uint32_t *nhits);
+void mgpu_term_hits_free(mgpu_term_hit_t *hits);
+
 #ifdef __cplusplus
 }
 #endif

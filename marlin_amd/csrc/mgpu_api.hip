@@ -16,6 +16,7 @@
 #include <mutex>
 #include <vector>
 #include "mgpu_types.h"
+#include "mg_lev.h"
 
 typedef unsigned long long u64;
 
@@ -41,6 +42,8 @@ void mgk_row_op(hipStream_t st, const unsigned long long *a, const unsigned long
 void mgk_scatter_list(hipStream_t st, const uint32_t *src, uint64_t n, unsigned long long *dst);
 void mgk_fetch(hipStream_t st, void *dst, const void *src_pinned, size_t bytes);
 void mgk_facet_hash(hipStream_t st, const SelJob *jobs, const void *outs, const uint32_t *list, const uint32_t *count, uint32_t cap);
+void mgk_term_scan(hipStream_t st, const TermJob *jobs, uint32_t njobs, uint32_t max_words, const uint32_t *term_chars,
+                   uint32_t *hits, uint32_t *count, uint32_t cap);
 }
 
 // Scratch of mgpu_posting_op_noalloc (include/marlin_gpu.h): two operand rows, the result row and the cardinality
@@ -437,6 +440,10 @@ struct mgpu_ctx {
     char *na_scratch = nullptr;                        // this device's g_noalloc_scratch (mgpu_posting_op_noalloc)
     char *na_pin = nullptr;                            // pinned bounce buffer of that entry point: [card 256 B | one row]
     struct Pending *pend = nullptr;                    // the batch in flight (execute_begin .. execute_end)
+    // term lookup (mgpu_lookup_terms): job table + term blob, hit list, counter; grown on demand, kept between calls
+    char *lk_in = nullptr; size_t lk_in_cap = 0;
+    uint32_t *lk_hits = nullptr; uint32_t lk_hits_cap = 0;
+    uint32_t *lk_count = nullptr;
     hipEvent_t ev[MGPU_NUM_STAGES + 1];
     int profiling;
     float stage_ms[MGPU_NUM_STAGES];
@@ -487,6 +494,9 @@ extern "C" void mgpu_ctx_destroy(mgpu_ctx_t *c) {
     if (c->pin_out) (void)hipHostFree(c->pin_out);
     if (c->na_pin) (void)hipHostFree(c->na_pin);
     (void)hipFree(c->pool); (void)hipFree(c->pool_used);
+    if (c->lk_in) (void)hipFree(c->lk_in);
+    if (c->lk_hits) (void)hipFree(c->lk_hits);
+    if (c->lk_count) (void)hipFree(c->lk_count);
     for (int i = 0; i <= MGPU_NUM_STAGES; i++) (void)hipEventDestroy(c->ev[i]);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1591,5 +1601,106 @@ extern "C" int mgpu_posting_op_noalloc(mgpu_ctx_t *c, mgpu_shard_t *s, int op, u
     HIPCHK(hipGetLastError());
     if (card) memcpy(card, c->na_pin, 8);
     if (out_words) memcpy(out_words, c->na_pin + 256, (size_t)sd.W * 8);
+    return MGPU_OK;
+}
+
+// ------------------------------------------------------------------ f-1: term lookup on the device
+struct mgpu_dict {
+    int device;
+    uint32_t *chars = nullptr, *off = nullptr, *wid = nullptr;
+    uint32_t nwords = 0; uint64_t nchars = 0;
+};
+
+extern "C" int mgpu_dict_create(int device, const uint32_t *chars, const uint32_t *word_off, const uint32_t *word_wid,
+                                uint32_t num_words, mgpu_dict_t **out) {
+    if (!out || !word_off || !word_wid || (num_words && !chars)) return fail(MGPU_E_ARG, "null argument");
+    // the kernel trusts the offset table: check it here, once
+    for (uint32_t i = 0; i < num_words; i++)
+        if (word_off[i + 1] < word_off[i]) return fail(MGPU_E_ARG, "word offsets must ascend");
+    const uint64_t nchars = num_words ? word_off[num_words] : 0;
+    if (word_off[0] != 0) return fail(MGPU_E_ARG, "word offsets must start at 0");
+    HIPCHK(hipSetDevice(device));
+    mgpu_dict *d = new mgpu_dict();
+    d->device = device; d->nwords = num_words; d->nchars = nchars;
+    auto bail = [&](hipError_t e) { mgpu_dict_destroy(d); return fail(MGPU_E_HIP, hipGetErrorString(e)); };
+    hipError_t e;
+    if ((e = hipMalloc((void **)&d->chars, (nchars + 4) * 4)) != hipSuccess) return bail(e);
+    if ((e = hipMalloc((void **)&d->off, ((size_t)num_words + 1) * 4)) != hipSuccess) return bail(e);
+    if ((e = hipMalloc((void **)&d->wid, ((size_t)num_words + 1) * 4)) != hipSuccess) return bail(e);
+    if (nchars && (e = hipMemcpy(d->chars, chars, nchars * 4, hipMemcpyHostToDevice)) != hipSuccess) return bail(e);
+    if ((e = hipMemcpy(d->off, word_off, ((size_t)num_words + 1) * 4, hipMemcpyHostToDevice)) != hipSuccess) return bail(e);
+    if (num_words && (e = hipMemcpy(d->wid, word_wid, (size_t)num_words * 4, hipMemcpyHostToDevice)) != hipSuccess) return bail(e);
+    *out = d;
+    return MGPU_OK;
+}
+
+extern "C" void mgpu_dict_destroy(mgpu_dict_t *d) {
+    if (!d) return;
+    (void)hipSetDevice(d->device);
+    if (d->chars) (void)hipFree(d->chars);
+    if (d->off) (void)hipFree(d->off);
+    if (d->wid) (void)hipFree(d->wid);
+    delete d;
+}
+
+extern "C" uint64_t mgpu_dict_bytes(const mgpu_dict_t *d) { return d ? (d->nchars + 4) * 4 + ((uint64_t)d->nwords + 1) * 8 : 0; }
+
+extern "C" void mgpu_term_hits_free(mgpu_term_hit_t *hits) { free(hits); }
+
+extern "C" int mgpu_lookup_terms(mgpu_ctx_t *c, const mgpu_term_lookup_t *lookups, int n, mgpu_term_hit_t **hits, uint32_t *nhits) {
+    if (!c || !hits || !nhits || n < 0 || (n && !lookups)) return fail(MGPU_E_ARG, "bad argument");
+    *hits = nullptr; *nhits = 0;
+    if (n == 0) return MGPU_OK;
+    if (c->pend) return fail(MGPU_E_ARG, "a batch is in flight on this context");
+    if (n > 65535) return fail(MGPU_E_LIMIT, "more than 65535 lookups per call (one grid row each)");
+    HIPCHK(hipSetDevice(c->device));
+    // job table + term blob
+    std::vector<TermJob> jobs((size_t)n);
+    std::vector<uint32_t> blob;
+    uint32_t max_words = 0;
+    for (int i = 0; i < n; i++) {
+        const mgpu_term_lookup_t &l = lookups[i];
+        if (!l.dict || !l.chars || l.len < 1 || l.len > MGPU_MAX_TERM_LEN) return fail(MGPU_E_ARG, "term of 0 or more than MGPU_MAX_TERM_LEN characters, or no dictionary");
+        if (l.dict->device != c->device) return fail(MGPU_E_ARG, "dictionary lives on another device");
+        TermJob &j = jobs[(size_t)i];
+        j.chars = l.dict->chars; j.off = l.dict->off; j.wid = l.dict->wid; j.nwords = l.dict->nwords;
+        j.term_off = (uint32_t)blob.size(); j.tlen = l.len; j.prefix = l.prefix ? 1 : 0; j.maxdist = mg_lev_maxdist(l.len); j.pad = 0;
+        blob.insert(blob.end(), l.chars, l.chars + l.len);
+        max_words = std::max(max_words, j.nwords);
+    }
+    const size_t jobs_b = (jobs.size() * sizeof(TermJob) + 255) & ~(size_t)255, blob_b = (blob.size() * 4 + 255) & ~(size_t)255;
+    if (c->lk_in_cap < jobs_b + blob_b) {
+        if (c->lk_in) { (void)hipFree(c->lk_in); c->lk_in = nullptr; c->lk_in_cap = 0; }
+        const size_t cap = std::max<size_t>(jobs_b + blob_b, 1u << 20);
+        HIPCHK(hipMalloc((void **)&c->lk_in, cap));
+        c->lk_in_cap = cap;
+    }
+    if (!c->lk_count) HIPCHK(hipMalloc((void **)&c->lk_count, 256));
+    if (!c->lk_hits) { HIPCHK(hipMalloc((void **)&c->lk_hits, (size_t)(1u << 20) * 12)); c->lk_hits_cap = 1u << 20; }
+    hipStream_t st = c->stream;
+    HIPCHK(hipMemcpyAsync(c->lk_in, jobs.data(), jobs.size() * sizeof(TermJob), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->lk_in + jobs_b, blob.data(), blob.size() * 4, hipMemcpyHostToDevice, st));
+    uint32_t total = 0;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        HIPCHK(hipMemsetAsync(c->lk_count, 0, 4, st));
+        mgk_term_scan(st, (const TermJob *)c->lk_in, (uint32_t)n, max_words, (const uint32_t *)(c->lk_in + jobs_b), c->lk_hits, c->lk_count, c->lk_hits_cap);
+        HIPCHK(hipMemcpyAsync(&total, c->lk_count, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipGetLastError());
+        if (total <= c->lk_hits_cap) break;
+        if (attempt == 1) return fail(MGPU_E_HIP, "term scan hit count changed between two runs");
+        // the list was too short: the counter says how long it has to be
+        (void)hipFree(c->lk_hits); c->lk_hits = nullptr; c->lk_hits_cap = 0;
+        HIPCHK(hipMalloc((void **)&c->lk_hits, (size_t)total * 12));
+        c->lk_hits_cap = total;
+    }
+    if (total) {
+        mgpu_term_hit_t *h = (mgpu_term_hit_t *)malloc((size_t)total * sizeof(mgpu_term_hit_t));
+        if (!h) return fail(MGPU_E_ARG, "out of host memory");
+        hipError_t e = hipMemcpy(h, c->lk_hits, (size_t)total * 12, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { free(h); return fail(MGPU_E_HIP, hipGetErrorString(e)); }
+        *hits = h;
+    }
+    *nhits = total;
     return MGPU_OK;
 }

@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include "mgpu_types.h"
+#include "mg_lev.h"
 
 typedef unsigned long long u64;
 typedef unsigned __int128 u128;
@@ -2368,6 +2369,47 @@ __global__ void k_clock_cal(unsigned long long *out) {
     while (w1 - w0 < 1000) w1 = wall_clock64();          // bounded: the wall clock always advances
     out[0] = w1 - w0; out[1] = clock64() - c0;
 }
+// ------------------------------------------------------------------ f-1: term lookup
+// dtrie_lookup_term's typo walk (dtrie.c:710-791) as a scan: one lane per dictionary word, scored on its own with the
+// walk's row arithmetic (mg_lev.h).  blockIdx.y = lookup, blockIdx.x = 256-word chunk of its dictionary (chunks past the
+// dictionary's end leave at once).  Matches are appended to one hit list with one atomic per wave; `count` keeps
+// counting past `cap`, so the host learns the size it needs.
+__global__ __launch_bounds__(MG_BLOCK) void k_term_scan(const TermJob *jobs, const uint32_t *term_chars,
+                                                        uint32_t *hits, uint32_t *count, uint32_t cap) {
+    __shared__ uint32_t s_term[MGPU_MAX_TERM_LEN + 1];
+    const TermJob *jp = &jobs[blockIdx.y];
+    const uint32_t nwords = jp->nwords;
+    if (blockIdx.x * MG_BLOCK >= nwords) return;
+    const uint32_t *chars = jp->chars, *off = jp->off, *wids = jp->wid;
+    const uint32_t term_off = jp->term_off;
+    int tlen = jp->tlen; const int prefix = jp->prefix, k = jp->maxdist;
+    if (tlen > MGPU_MAX_TERM_LEN) tlen = MGPU_MAX_TERM_LEN;          // the host refuses longer terms; never index past s_term
+    for (int i = threadIdx.x; i < tlen; i += MG_BLOCK) s_term[i] = term_chars[term_off + i];
+    __syncthreads();
+    const uint32_t w = blockIdx.x * MG_BLOCK + threadIdx.x;
+    uint32_t dist = MG_LEV_NOMATCH, wid = 0;
+    if (w < nwords) {
+        const uint32_t o0 = off[w], o1 = off[w + 1];
+        // the walk ends by itself a few characters past the term's length; the bounds only keep the loop finite and
+        // inside the array on a damaged offset table (mgpu_dict_create checks the table)
+        int wlen = o1 > o0 ? (int)(o1 - o0) : 0;
+        if (wlen > 4096) wlen = 4096;
+        if (wlen > 0) dist = mg_lev_word((const uint32_t *)s_term, tlen, k, prefix, chars + o0, wlen);
+        wid = wids[w];
+    }
+    const bool hit = dist != MG_LEV_NOMATCH;
+    const u64 m = __ballot(hit);
+    if (!m) return;
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+    uint32_t at = 0;
+    if (lane == leader) at = atomicAdd(count, (uint32_t)__popcll(m));
+    at = __shfl(at, leader, 64);
+    if (hit) {
+        const uint32_t idx = at + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+        if (idx < cap) { hits[3 * (size_t)idx] = blockIdx.y; hits[3 * (size_t)idx + 1] = wid; hits[3 * (size_t)idx + 2] = dist; }
+    }
+}
+
 extern "C" {
 // diagnostic: ticks of wall_clock64 and of the shader clock over the same interval, plus the host's view in ns
 int mgk_debug_clock_cal(unsigned long long *out3) {
@@ -2394,6 +2436,11 @@ int mgk_debug_phases(int on, unsigned long long *out16) {
     if (hipMemcpyToSymbol(HIP_SYMBOL(mg_dbg_acc), z, sizeof(z)) != hipSuccess) return -1;
     if (hipMemcpyToSymbol(HIP_SYMBOL(mg_dbg_on), &on, sizeof(int)) != hipSuccess) return -1;
     return 0;
+}
+void mgk_term_scan(hipStream_t st, const TermJob *jobs, uint32_t njobs, uint32_t max_words, const uint32_t *term_chars,
+                   uint32_t *hits, uint32_t *count, uint32_t cap) {
+    if (!njobs || !max_words) return;
+    hipLaunchKernelGGL(k_term_scan, dim3((max_words + MG_BLOCK - 1) / MG_BLOCK, njobs), dim3(MG_BLOCK), 0, st, jobs, term_chars, hits, count, cap);
 }
 void mgk_scatter(hipStream_t st, const ScatterItem *items, uint32_t nitems) {
     if (!nitems) return;

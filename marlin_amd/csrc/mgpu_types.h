@@ -187,3 +187,12 @@ struct ScatterItem {                 // one chunk of a sorted docid list OR-ed i
     uint32_t n;
     uint32_t pad;
 };
+
+// one (term, dictionary) pair of the device term lookup (k_term_scan)
+struct TermJob {
+    const uint32_t *chars, *off, *wid;   // the dictionary: flat code points, word offsets (nwords + 1), word ids
+    uint32_t nwords;
+    uint32_t term_off;                   // the term's code points in the term blob
+    int32_t tlen, prefix, maxdist;
+    uint32_t pad;
+};

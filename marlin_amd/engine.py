@@ -147,14 +147,18 @@ class GpuEngine:
             raise GpuError("msq_execute_batch: %d %s" % (rc, self.lib.mgpu_last_error().decode()))
         return outs
 
-    def prepare(self, pqs, capture=0):
+    def prepare(self, pqs, capture=0, device_lookup=False):
         """term lookups + filter leaf resolution for a batch; returns a handle for execute_prepared.
-        The parsed queries must stay alive as long as the handle."""
+        The parsed queries must stay alive as long as the handle.  device_lookup: the typo walks of the term lookup
+        run on the GPU (msq_prepare_batch_dev, row f-1) instead of on the host trie."""
         ns = self.index.num_shards
         nq = len(pqs)
         qarr = (C.POINTER(ffi.Query) * nq)(*[p.q for p in pqs])
         h = C.c_void_p()
-        rc = self.lib.msq_prepare_batch(self._marr, ns, qarr, nq, capture, C.byref(h))
+        if device_lookup:
+            rc = self.lib.msq_prepare_batch_dev(self.ctx, self._marr, ns, qarr, nq, capture, C.byref(h))
+        else:
+            rc = self.lib.msq_prepare_batch(self._marr, ns, qarr, nq, capture, C.byref(h))
         if rc:
             raise GpuError("msq_prepare_batch: %d %s" % (rc, self.lib.mgpu_last_error().decode()))
         return (h, nq, pqs)
@@ -212,13 +216,20 @@ class GpuEngine:
     def free_raw(self, outs):
         self.lib.m_sqresult_free_batch(outs, len(outs))
 
-    def search(self, pqs, capture=0):
+    def search(self, pqs, capture=0, device_lookup=False):
         """list of parsed queries -> list of assembled result dicts"""
         single = not isinstance(pqs, (list, tuple))
         if single:
             pqs = [pqs]
         ns = self.index.num_shards
-        outs = self.execute_raw(pqs, capture)
+        if device_lookup:
+            prep = self.prepare(pqs, capture, device_lookup=True)
+            try:
+                outs = self.execute_prepared(prep)
+            finally:
+                self.free_prepared(prep)
+        else:
+            outs = self.execute_raw(pqs, capture)
         res = []
         for i, pq in enumerate(pqs):
             sub = (ffi.SqResult * ns).from_address(C.addressof(outs) + i * ns * C.sizeof(ffi.SqResult))

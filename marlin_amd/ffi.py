@@ -98,7 +98,18 @@ class Result(C.Structure):
 class Mirror(C.Structure):
     """mmirror_t (marlin_amd/host/mplan.h): the posting-id scheme of one shard mirror"""
     _fields_ = [("s", C.c_void_p), ("g", C.c_void_p), ("device", C.c_int), ("W", C.c_uint32), ("T", C.c_uint32),
-                ("fbase", C.c_uint32 * M_MAX_FIELDS), ("bbase", C.c_uint32), ("num_postings", C.c_uint32)]
+                ("fbase", C.c_uint32 * M_MAX_FIELDS), ("bbase", C.c_uint32), ("num_postings", C.c_uint32),
+                ("gd", C.c_void_p)]
+
+
+class TermLookup(C.Structure):
+    """mgpu_term_lookup_t (include/marlin_gpu.h)"""
+    _fields_ = [("dict", C.c_void_p), ("chars", C.POINTER(C.c_uint32)), ("len", C.c_int32), ("prefix", C.c_int32)]
+
+
+class TermHit(C.Structure):
+    """mgpu_term_hit_t"""
+    _fields_ = [("lookup", C.c_uint32), ("wid", C.c_uint32), ("dist", C.c_uint32)]
 
 
 class ShardStruct(C.Structure):
@@ -223,6 +234,14 @@ def load():
         "mmirror_gpu": (vp, [vp]),
         "msq_execute_batch": (ci, [vp, C.POINTER(vp), ci, C.POINTER(C.POINTER(Query)), ci, ci, C.POINTER(SqResult)]),
         "msq_prepare_batch": (ci, [C.POINTER(vp), ci, C.POINTER(C.POINTER(Query)), ci, ci, C.POINTER(vp)]),
+        "msq_prepare_batch_dev": (ci, [vp, C.POINTER(vp), ci, C.POINTER(C.POINTER(Query)), ci, ci, C.POINTER(vp)]),
+        "mgpu_dict_create": (ci, [ci, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), cu, C.POINTER(vp)]),
+        "mgpu_dict_destroy": (None, [vp]),
+        "mgpu_dict_bytes": (C.c_uint64, [vp]),
+        "mgpu_lookup_terms": (ci, [vp, C.POINTER(TermLookup), ci, C.POINTER(C.POINTER(TermHit)), C.POINTER(cu)]),
+        "mgpu_term_hits_free": (None, [C.POINTER(TermHit)]),
+        "mdict_export_words": (ci, [vp, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(cu)]),
+        "mdict_lookup_mode": (ci, [C.POINTER(Term)]),
         "msq_execute_prepared": (ci, [vp, vp, C.POINTER(SqResult)]),
         "msq_prepared_free": (None, [vp]),
         "msq_run_pipeline": (ci, [C.POINTER(vp), ci, C.POINTER(vp), ci, ci, ci, C.POINTER(C.c_long)]),

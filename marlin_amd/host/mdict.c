@@ -258,6 +258,11 @@ static void lookup_typo(const mdict_t *d, const m_term_t *t, m_termresult_t *tr)
     free(rows);
 }
 
+int mdict_lookup_mode(const m_term_t *t) {
+    if (t->prefix && t->word.length <= M_LEVLIMIT) return 0;
+    return t->typos ? 2 : 1;
+}
+
 void mdict_lookup_term(const mdict_t *d, const m_term_t *t, m_termresult_t *tr) {
     tr->twid = 0;
     m_u32map_init(&tr->wordids);
@@ -281,3 +286,44 @@ void mdict_lookup_term(const mdict_t *d, const m_term_t *t, m_termresult_t *tr) 
 }
 
 void m_termresult_free(m_termresult_t *tr) { m_u32map_free(&tr->wordids); }
+
+/* Every word of the dictionary as a flat character array in trie (depth-first) order, so that neighbours share
+ * prefixes: the layout the device-side term scan reads (marlin_amd/csrc/mg_lev.h).  off has n + 1 entries. */
+int mdict_export_words(const mdict_t *d, uint32_t **chars_out, uint32_t **off_out, uint32_t **wid_out, uint32_t *n_out) {
+    uint32_t n = d->word_count, cap = 1024, nchars = 0, nw = 0;
+    uint32_t *chars = malloc(sizeof(uint32_t) * cap);
+    uint32_t *off = malloc(sizeof(uint32_t) * ((size_t)n + 1));
+    uint32_t *wid = malloc(sizeof(uint32_t) * ((size_t)n + 1));
+    /* explicit DFS: stack of (node, depth); path[] holds the characters of the current path */
+    uint32_t scap = 1024, top = 0;
+    uint32_t *st_node = malloc(sizeof(uint32_t) * scap), *st_depth = malloc(sizeof(uint32_t) * scap);
+    uint32_t pcap = 256;
+    m_chr_t *path = malloc(sizeof(m_chr_t) * pcap);
+    if (!chars || !off || !wid || !st_node || !st_depth || !path) goto oom;
+    for (uint32_t k = d->first_child[0]; k; k = d->next_sib[k]) {
+        if (top == scap) { scap *= 2; st_node = realloc(st_node, sizeof(uint32_t) * scap); st_depth = realloc(st_depth, sizeof(uint32_t) * scap); if (!st_node || !st_depth) goto oom; }
+        st_node[top] = k; st_depth[top++] = 1;
+    }
+    while (top) {
+        uint32_t x = st_node[--top], dep = st_depth[top];
+        if (dep > pcap) { pcap *= 2; path = realloc(path, sizeof(m_chr_t) * pcap); if (!path) goto oom; }
+        path[dep - 1] = d->ch[x];
+        if (d->wid[x] && nw < n) {
+            if (nchars + dep > cap) { while (nchars + dep > cap) cap *= 2; chars = realloc(chars, sizeof(uint32_t) * cap); if (!chars) goto oom; }
+            off[nw] = nchars; wid[nw] = d->wid[x];
+            for (uint32_t i = 0; i < dep; i++) chars[nchars++] = (uint32_t)path[i];
+            nw++;
+        }
+        for (uint32_t k = d->first_child[x]; k; k = d->next_sib[k]) {
+            if (top == scap) { scap *= 2; st_node = realloc(st_node, sizeof(uint32_t) * scap); st_depth = realloc(st_depth, sizeof(uint32_t) * scap); if (!st_node || !st_depth) goto oom; }
+            st_node[top] = k; st_depth[top++] = dep + 1;
+        }
+    }
+    off[nw] = nchars;
+    free(st_node); free(st_depth); free(path);
+    *chars_out = chars; *off_out = off; *wid_out = wid; *n_out = nw;
+    return 0;
+oom:
+    free(chars); free(off); free(wid); free(st_node); free(st_depth); free(path);
+    return -1;
+}

@@ -52,6 +52,10 @@ uint32_t mdict_lookup_exact(const mdict_t *d, const m_word_t *w);
 /* dtrie_lookup_term (dtrie.c:805); caller owns *tr and must m_termresult_free it */
 void     mdict_lookup_term(const mdict_t *d, const m_term_t *t, m_termresult_t *tr);
 void     m_termresult_free(m_termresult_t *tr);
+/* all words, flat, in trie order: chars[off[i] .. off[i+1]) are the characters of the word with id wid[i]; the caller frees */
+int      mdict_export_words(const mdict_t *d, uint32_t **chars_out, uint32_t **off_out, uint32_t **wid_out, uint32_t *n_out);
+/* which lookup mode dtrie_lookup_term takes for a term (dtrie.c:805-823): 0 = twid, 1 = no typos, 2 = typo walk */
+int      mdict_lookup_mode(const m_term_t *t);
 
 #ifdef __cplusplus
 }

@@ -64,12 +64,21 @@ int mmirror_create(const mshard_t *s, int device, mmirror_t **out) {
     int rc = mgpu_shard_create(device, &d, &m->g);
     free(off); free(doc);
     if (rc) { free(m); return rc; }
+    /* the dictionary as a flat word list, for the device-side term lookup */
+    if (s->dict) {
+        uint32_t *chars = NULL, *woff = NULL, *wwid = NULL, nw = 0;
+        if (mdict_export_words(s->dict, &chars, &woff, &wwid, &nw)) { mgpu_shard_destroy(m->g); free(m); return MGPU_E_ARG; }
+        rc = mgpu_dict_create(device, chars, woff, wwid, nw, &m->gd);
+        free(chars); free(woff); free(wwid);
+        if (rc) { mgpu_shard_destroy(m->g); free(m); return rc; }
+    }
     *out = m;
     return 0;
 }
 
 void mmirror_destroy(mmirror_t *m) {
     if (!m) return;
+    mgpu_dict_destroy(m->gd);
     mgpu_shard_destroy(m->g);
     free(m);
 }
@@ -212,18 +221,24 @@ static int lower_filter(const mmirror_t *m, const m_filter_t *f, mplan_t *pl) {
     }
 }
 
-int mplan_build(const mmirror_t *m, const m_query_t *q, int capture, mplan_t *pl) {
+/* pre (may be NULL): term results that the device already produced; pre_have[t] says which */
+static int mplan_build_with(const mmirror_t *m, const m_query_t *q, int capture, mplan_t *pl, m_termresult_t *pre, const uint8_t *pre_have) {
     if (q->num_terms > MGPU_MAX_TERMS || q->num_words > MGPU_MAX_WORDS) { memset(pl, 0, sizeof(*pl)); return MGPU_E_LIMIT; }
     const mshard_t *s = m->s;
-    /* lookup_terms (squery.c:144-167): the trie walk stays on the host */
+    /* lookup_terms (squery.c:144-167): the trie walk stays on the host unless the device did it */
     m_termresult_t tr[M_MAX_QTERMS];
     uint32_t exact_wid[M_MAX_QWORDS];
-    for (int t = 0; t < q->num_terms; t++) mdict_lookup_term(s->dict, &q->terms[t], &tr[t]);
+    for (int t = 0; t < q->num_terms; t++) {
+        if (pre && pre_have[t]) { tr[t] = pre[t]; memset(&pre[t], 0, sizeof(pre[t])); }      /* ownership moves here */
+        else mdict_lookup_term(s->dict, &q->terms[t], &tr[t]);
+    }
     for (int i = 0; i < q->num_words; i++) exact_wid[i] = mdict_lookup_exact(s->dict, &q->words[i]);
     int rc = mplan_from_terms(m, q, tr, exact_wid, capture, pl);
     for (int t = 0; t < q->num_terms; t++) m_termresult_free(&tr[t]);
     return rc;
 }
+
+int mplan_build(const mmirror_t *m, const m_query_t *q, int capture, mplan_t *pl) { return mplan_build_with(m, q, capture, pl, NULL, NULL); }
 
 /* Everything of the plan after the trie walk.  tr[t] = dtrie_lookup_term's result for term t (its wordids map
  * is extended here with the words under a twid, as set_wids_under_twid does, squery.c:62-70); exact_wid[i] =
@@ -331,12 +346,14 @@ void msq_set_plan_threads(int n) { msq_plan_threads = n; }
 struct plan_job {
     mmirror_t *const *mirrors; int num_shards; const m_query_t *const *queries; int capture;
     mplan_t *plans; mgpu_plan_t *gp; mgpu_shard_t **gs; int lo, hi, rc;
+    m_termresult_t *pre; uint8_t *pre_have;        /* per (query, shard) M_MAX_QTERMS entries each, or NULL */
 };
 static void *plan_worker(void *arg) {
     struct plan_job *j = arg;
     for (int i = j->lo; i < j->hi; i++) {
         int qi = i / j->num_shards, sidx = i % j->num_shards;
-        int rc = mplan_build(j->mirrors[sidx], j->queries[qi], j->capture, &j->plans[i]);
+        int rc = mplan_build_with(j->mirrors[sidx], j->queries[qi], j->capture, &j->plans[i],
+                                  j->pre ? j->pre + (size_t)i * M_MAX_QTERMS : NULL, j->pre ? j->pre_have + (size_t)i * M_MAX_QTERMS : NULL);
         if (rc) j->rc = rc;
         j->gp[i] = j->plans[i].p;
         j->gs[i] = j->mirrors[sidx]->g;
@@ -353,8 +370,8 @@ struct msq_prepared {
 };
 
 /* lookup_terms (squery.c:144-167) + filter leaf resolution for every (query, shard) pair */
-int msq_prepare_batch(mmirror_t *const *mirrors, int num_shards, const m_query_t *const *queries,
-                      int nq, int capture, msq_prepared_t **out) {
+static int prepare_common(mmirror_t *const *mirrors, int num_shards, const m_query_t *const *queries,
+                          int nq, int capture, m_termresult_t *pre, uint8_t *pre_have, msq_prepared_t **out) {
     int n = nq * num_shards;
     msq_prepared_t *pp = calloc(1, sizeof(*pp));
     pp->n = n; pp->nq = nq; pp->num_shards = num_shards; pp->mirrors = mirrors;
@@ -374,6 +391,7 @@ int msq_prepare_batch(mmirror_t *const *mirrors, int num_shards, const m_query_t
         jobs[t].mirrors = mirrors; jobs[t].num_shards = num_shards; jobs[t].queries = queries;
         jobs[t].capture = capture; jobs[t].plans = pp->plans; jobs[t].gp = pp->gp; jobs[t].gs = pp->gs;
         jobs[t].lo = (int)((long)n * t / nthreads); jobs[t].hi = (int)((long)n * (t + 1) / nthreads); jobs[t].rc = 0;
+        jobs[t].pre = pre; jobs[t].pre_have = pre_have;
     }
     if (nthreads == 1) plan_worker(&jobs[0]);
     else {
@@ -383,6 +401,63 @@ int msq_prepare_batch(mmirror_t *const *mirrors, int num_shards, const m_query_t
     for (int t = 0; t < nthreads; t++) if (jobs[t].rc) rc = jobs[t].rc;
     if (rc) { msq_prepared_free(pp); pp = NULL; }
     *out = pp;
+    return rc;
+}
+
+int msq_prepare_batch(mmirror_t *const *mirrors, int num_shards, const m_query_t *const *queries,
+                      int nq, int capture, msq_prepared_t **out) {
+    return prepare_common(mirrors, num_shards, queries, nq, capture, NULL, NULL, out);
+}
+
+int msq_prepare_batch_dev(mgpu_ctx_t *ctx, mmirror_t *const *mirrors, int num_shards, const m_query_t *const *queries,
+                          int nq, int capture, msq_prepared_t **out) {
+    *out = NULL;
+    const int n = nq * num_shards;
+    if (n <= 0) return prepare_common(mirrors, num_shards, queries, nq, capture, NULL, NULL, out);
+    m_termresult_t *pre = calloc((size_t)n * M_MAX_QTERMS, sizeof(*pre));
+    uint8_t *have = calloc((size_t)n * M_MAX_QTERMS, 1);
+    /* every term that dtrie_lookup_term would walk the trie for (mode 2) becomes one device lookup */
+    size_t nl = 0;
+    for (int i = 0; i < n; i++) {
+        const m_query_t *q = queries[i / num_shards];
+        if (!mirrors[i % num_shards]->gd || q->num_terms > M_MAX_QTERMS) continue;
+        for (int t = 0; t < q->num_terms; t++)
+            if (mdict_lookup_mode(&q->terms[t]) == 2 && q->terms[t].word.length >= 1 && q->terms[t].word.length <= MGPU_MAX_TERM_LEN) nl++;
+    }
+    mgpu_term_lookup_t *lk = malloc(sizeof(*lk) * (nl ? nl : 1));
+    uint32_t *slot = malloc(sizeof(uint32_t) * (nl ? nl : 1));          /* lookup -> index into pre[] */
+    nl = 0;
+    for (int i = 0; i < n; i++) {
+        const m_query_t *q = queries[i / num_shards];
+        if (!mirrors[i % num_shards]->gd || q->num_terms > M_MAX_QTERMS) continue;
+        for (int t = 0; t < q->num_terms; t++) {
+            const m_term_t *tm = &q->terms[t];
+            if (mdict_lookup_mode(tm) != 2 || tm->word.length < 1 || tm->word.length > MGPU_MAX_TERM_LEN) continue;
+            lk[nl].dict = mirrors[i % num_shards]->gd; lk[nl].chars = tm->word.chars; lk[nl].len = tm->word.length; lk[nl].prefix = tm->prefix;
+            slot[nl] = (uint32_t)((size_t)i * M_MAX_QTERMS + (size_t)t);
+            have[slot[nl]] = 1;                                      /* an empty result is a result too */
+            nl++;
+        }
+    }
+    int rc = 0;
+    /* at most 65535 lookups per call */
+    for (size_t lo = 0; lo < nl && !rc; lo += 65535) {
+        const int cnt = (int)(nl - lo < 65535 ? nl - lo : 65535);
+        mgpu_term_hit_t *hits = NULL; uint32_t nh = 0;
+        rc = mgpu_lookup_terms(ctx, lk + lo, cnt, &hits, &nh);
+        if (rc) break;
+        for (uint32_t h = 0; h < nh; h++) {
+            if (hits[h].lookup >= (uint32_t)cnt) { rc = MGPU_E_HIP; break; }
+            m_termresult_t *tr = &pre[slot[lo + hits[h].lookup]];
+            /* add_wordid_to_result (dtrie.c:633-640): least distance */
+            if ((int)hits[h].dist < m_u32map_get(&tr->wordids, hits[h].wid, 0xFF)) m_u32map_set(&tr->wordids, hits[h].wid, (int32_t)hits[h].dist);
+        }
+        mgpu_term_hits_free(hits);
+    }
+    free(lk); free(slot);
+    if (!rc) rc = prepare_common(mirrors, num_shards, queries, nq, capture, pre, have, out);
+    for (size_t i = 0; i < (size_t)n * M_MAX_QTERMS; i++) if (pre[i].wordids.cap) m_termresult_free(&pre[i]);
+    free(pre); free(have);
     return rc;
 }
 

@@ -26,6 +26,7 @@ typedef struct mmirror {
     uint32_t  fbase[M_MAX_FIELDS];       /* pid of field f's first facet posting */
     uint32_t  bbase;                     /* pid of bool field 0 / false */
     uint32_t  num_postings;
+    mgpu_dict_t *gd;                     /* the shard's dictionary on the device (term lookup, row f-1); NULL if s->dict is NULL */
 } mmirror_t;
 
 /* pid 0 = all docs, 1..W = wid2bmap, W+1..W+T = twid2bmap, then facetid2bmap, then boolid2bmap */
@@ -71,6 +72,12 @@ int  msq_execute_prepared(mgpu_ctx_t *ctx, const msq_prepared_t *pp, m_sqresult_
  * collect waits for it and decodes; pp must stay alive in between */
 int  msq_submit_prepared(mgpu_ctx_t *ctx, const msq_prepared_t *pp);
 int  msq_collect_prepared(mgpu_ctx_t *ctx, const msq_prepared_t *pp, m_sqresult_t *outs);
+/* msq_prepare_batch with the typo walks of lookup_terms run on the device: ONE mgpu_lookup_terms call scores every
+ * (query, shard, term) that dtrie_lookup_term would walk the trie for (dtrie.c:763-791); the twid and no-typo modes,
+ * exact word ids and the rest of the plan stay on the host.  ctx must be idle (no batch in flight) and on the mirrors'
+ * device. */
+int  msq_prepare_batch_dev(mgpu_ctx_t *ctx, mmirror_t *const *mirrors, int num_shards, const m_query_t *const *queries,
+                           int nq, int capture, msq_prepared_t **out);
 void msq_prepared_free(msq_prepared_t *pp);
 /* serving loop: nctx contexts = nctx batches in flight, two contexts per host thread (a thread submits its next
  * batch before it decodes and merges the current one); step i runs batch (first + i) % nprep through
