@@ -1651,7 +1651,7 @@ extern "C" int mgpu_lookup_terms(mgpu_ctx_t *c, const mgpu_term_lookup_t *lookup
     if (!c || !hits || !nhits || n < 0 || (n && !lookups)) return fail(MGPU_E_ARG, "bad argument");
     *hits = nullptr; *nhits = 0;
     if (n == 0) return MGPU_OK;
-    if (c->pend) return fail(MGPU_E_ARG, "a batch is in flight on this context");
+    if (c->pend && c->pend->active) return fail(MGPU_E_ARG, "a batch is in flight on this context");
     if (n > 65535) return fail(MGPU_E_LIMIT, "more than 65535 lookups per call (one grid row each)");
     HIPCHK(hipSetDevice(c->device));
     // job table + term blob

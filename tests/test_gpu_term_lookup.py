@@ -117,7 +117,7 @@ def test_scan_equals_trie_walk_datagen_and_queries():
             if len(w) > 2:
                 i = rng.randrange(len(w) - 1)
                 words.append(w[:i] + w[i + 1] + w[i] + w[i + 2:])
-        assert check_terms(ix, eng, sorted(set(words))) > 100
+        assert check_terms(ix, eng, sorted(set(words))) > 10
         qs = [{"q": "aaaaaab bbbbbbc", "rankBy": {"num": "desc"}}, {"q": "aaaaaaa bbbbbbb ccccccc", "rankBy": {"id": "asc"}},
               {"q": "aaaaaax", "rankBy": {"id": "asc"}, "hitsPerPage": 30}, {"q": "bbbbbb attr", "sortBy": {"num": "asc"}},
               {"q": "zzzzzzy yyyyyyy", "rankBy": {"num": "desc"}}, {"q": "aa"}, {"q": ""}, {"q": "aaaaaaa", "typos": False}]
