@@ -8,8 +8,9 @@
  * free), and two set-up calls a maintainer adds where a shard is opened / after a bulk commit (sindex.c:246):
  *      int  mgpu_shim_attach_shard(struct shard *s, int device);   -- mirror the shard's LMDB into HBM
  *      void mgpu_shim_detach_shard(struct shard *s);
- * What stays on the host is what north_star keeps there: the dtrie walk (dtrie_lookup_term / dtrie_lookup_exact),
- * LMDB, filter and agg parsing.  Everything between lookup_terms and the filled squery_result runs in
+ * What stays on the host is what north_star keeps there: the exact descents of the dtrie (twid / no-typo lookups,
+ * dtrie_lookup_exact), LMDB, filter and agg parsing.  The typo walk of dtrie_lookup_term (dtrie.c:763-791) runs on the
+ * device against a flat copy of the shard's dictionary (row f-1: mgpu_lookup_terms).  Everything between lookup_terms and the filled squery_result runs in
  * libmarlin_gpu.so through the host library (mplan_from_terms -> msq_execute_plan).
  *
  * There is NO CPU fallback in here: without an attached mirror, or on a GPU error, the shard reports zero hits and
@@ -138,6 +139,47 @@ void mgpu_shim_detach_shard(struct shard *s) {
     pthread_rwlock_unlock(&g_shards_lock);
 }
 
+/* Every word of the shard's dtrie as a flat list (the input of mgpu_dict_create): a depth-first walk over the mapped
+ * nodes with the layout of dtrie.h:36-51 -- children sorted by character, the word id behind the child array when
+ * has_wid is set (get_widpos, dtrie.c:24-28).  Runs under the trie's read lock. */
+struct dict_out { uint32_t *chars, *off, *wid; uint32_t n, nchars, ccap, wcap; chr_t *path; uint32_t pcap; int oom; };
+static void dict_walk(struct dtrie *dt, const struct dnode *n, uint32_t depth, struct dict_out *o) {
+    if (o->oom) return;
+    if (n->has_wid && depth) {
+        const uint32_t *widpos = (const uint32_t *)((const uint8_t *)n + sizeof(struct dnode) + n->num_child * sizeof(struct dnode_ptr));
+        if (o->n + 1 >= o->wcap) {
+            o->wcap = o->wcap ? o->wcap * 2 : 4096;
+            o->off = realloc(o->off, sizeof(uint32_t) * ((size_t)o->wcap + 1)); o->wid = realloc(o->wid, sizeof(uint32_t) * o->wcap);
+        }
+        if (o->nchars + depth > o->ccap) {
+            while (o->nchars + depth > o->ccap) o->ccap = o->ccap ? o->ccap * 2 : 65536;
+            o->chars = realloc(o->chars, sizeof(uint32_t) * o->ccap);
+        }
+        if (!o->off || !o->wid || !o->chars) { o->oom = 1; return; }
+        o->off[o->n] = o->nchars; o->wid[o->n] = *widpos; o->n++;
+        for (uint32_t i = 0; i < depth; i++) o->chars[o->nchars++] = (uint32_t)o->path[i];
+    }
+    for (uint32_t c = 0; c < n->num_child; c++) {
+        if (depth + 1 > o->pcap) { o->pcap = o->pcap ? o->pcap * 2 : 256; o->path = realloc(o->path, sizeof(chr_t) * o->pcap); if (!o->path) { o->oom = 1; return; } }
+        o->path[depth] = n->child[c].c;
+        dict_walk(dt, (const struct dnode *)(dt->map + n->child[c].nid.offset), depth + 1, o);
+    }
+}
+static int attach_dict(struct dtrie *dt, int device, mgpu_dict_t **out) {
+    struct dict_out o;
+    memset(&o, 0, sizeof(o));
+    pthread_rwlock_rdlock(&dt->trie_lock);
+    dict_walk(dt, dt->root, 0, &o);
+    pthread_rwlock_unlock(&dt->trie_lock);
+    int rc = MGPU_E_LIMIT;
+    if (!o.oom) {
+        if (!o.off) o.off = calloc(1, sizeof(uint32_t));
+        if (o.off) { o.off[o.n] = o.nchars; rc = mgpu_dict_create(device, o.chars, o.off, o.wid ? o.wid : o.off, o.n, out); }
+    }
+    free(o.chars); free(o.off); free(o.wid); free(o.path);
+    return rc;
+}
+
 /* Mirrors one shard: every posting, docdata blob and num_dbi pair of its LMDB environment, read inside one read
  * transaction (a consistent snapshot against the single writer, sindex.c:184-254).  Replaces an earlier mirror of the
  * same shard.  Returns 0 or an MGPU_E_* code. */
@@ -192,6 +234,12 @@ int mgpu_shim_attach_shard(struct shard *s, int device) {
         M_ERR("gpu squery: mmirror_create for shard %d: %s", s->shard_id, mgpu_last_error());
         mshard_free(src);
         return rc ? rc : MGPU_E_LIMIT;
+    }
+    /* the shard's dictionary for the device-side typo walk (the bridged mshard_t carries no dictionary of its own) */
+    if ((rc = attach_dict(si->trie, device, &mirror->gd))) {
+        M_ERR("gpu squery: dictionary of shard %d: %s", s->shard_id, mgpu_last_error());
+        mmirror_destroy(mirror); mshard_free(src);
+        return rc;
     }
     mgpu_shim_detach_shard(s);
     pthread_rwlock_wrlock(&g_shards_lock);
@@ -326,23 +374,48 @@ void execute_squery(void *w) {
         return;
     }
 
-    /* unchanged host work: the trie walk (lookup_terms, squery.c:144-167) */
+    /* lookup_terms (squery.c:144-167).  dtrie_lookup_term's three modes (dtrie.c:805-823): short prefixes and terms
+     * without typos are exact descents and stay with the dtrie; the typo walk goes to the device, all terms in one call */
     struct sindex *si = sq->shard->sindex;
     m_termresult_t tr[M_MAX_QTERMS];
     uint32_t exact_wid[M_MAX_QWORDS];
+    mgpu_term_lookup_t lk[M_MAX_QTERMS]; int lk_term[M_MAX_QTERMS]; int nlk = 0;
     for (int t = 0; t < num_terms; t++) {
-        termresult_t *r = dtrie_lookup_term(si->trie, kv_A(q->terms, t));
-        tr[t].twid = r->twid;
+        term_t *tm = kv_A(q->terms, t);
+        tr[t].twid = 0;
         m_u32map_init(&tr[t].wordids);
+        const int walk = tm->typos && !(tm->prefix && tm->word->length <= LEVLIMIT) && mirror->gd &&
+                         tm->word->length >= 1 && tm->word->length <= MGPU_MAX_TERM_LEN;
+        if (walk) {
+            lk[nlk].dict = mirror->gd; lk[nlk].chars = (const uint32_t *)tm->word->chars; lk[nlk].len = tm->word->length; lk[nlk].prefix = tm->prefix;
+            lk_term[nlk++] = t;
+            continue;
+        }
+        termresult_t *r = dtrie_lookup_term(si->trie, tm);
+        tr[t].twid = r->twid;
         uint32_t wid; int dist;
         kh_foreach(r->wordids, wid, dist, { m_u32map_set(&tr[t].wordids, wid, dist); });
         termresult_free(r);
     }
     for (int i = 0; i < q->num_words; i++) exact_wid[i] = dtrie_lookup_exact(si->trie, kv_A(q->words, i));
+    int rc = 0;
+    int slot = 0;
+    mgpu_ctx_t *ctx = ctx_acquire(device, &slot);
+    if (!ctx) rc = MGPU_E_HIP;
+    if (!rc && nlk) {
+        mgpu_term_hit_t *hits = NULL; uint32_t nh = 0;
+        rc = mgpu_lookup_terms(ctx, lk, nlk, &hits, &nh);
+        for (uint32_t h = 0; !rc && h < nh; h++) {
+            if (hits[h].lookup >= (uint32_t)nlk) { rc = MGPU_E_HIP; break; }
+            m_u32map_t *m = &tr[lk_term[hits[h].lookup]].wordids;
+            if ((int)hits[h].dist < m_u32map_get(m, hits[h].wid, 0xFF)) m_u32map_set(m, hits[h].wid, (int32_t)hits[h].dist);
+        }
+        mgpu_term_hits_free(hits);
+    }
 
     /* struct query -> plan */
     m_query_t *mq = lower_query(q, num_facets);
-    int rc = lower_aggs(q->agg, mq);
+    if (!rc) rc = lower_aggs(q->agg, mq);
     mplan_t plan;
     memset(&plan, 0, sizeof(plan));
     if (!rc) rc = mplan_from_terms(mirror, mq, tr, exact_wid, 0, &plan);
@@ -351,15 +424,8 @@ void execute_squery(void *w) {
     /* everything from get_matching_docids to the top-2N cut (squery.c:480-517), on the GPU */
     m_sqresult_t out;
     memset(&out, 0, sizeof(out));
-    if (!rc) {
-        int slot = 0;
-        mgpu_ctx_t *ctx = ctx_acquire(device, &slot);
-        if (!ctx) rc = MGPU_E_HIP;
-        else {
-            rc = msq_execute_plan(ctx, mirror, mq, &plan, sq->shard_idx, &out);
-            ctx_release(device, slot);
-        }
-    }
+    if (!rc) rc = msq_execute_plan(ctx, mirror, mq, &plan, sq->shard_idx, &out);
+    if (ctx) ctx_release(device, slot);
     pthread_rwlock_unlock(&g_shards_lock);
 
     if (rc) {
