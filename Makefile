@@ -8,7 +8,7 @@ REF     ?= /root/reference
 HOST_SRC = marlin_amd/host/mdict.c marlin_amd/host/mshard.c marlin_amd/host/manalyzer.c \
            marlin_amd/host/mquery.c marlin_amd/host/mplan.c marlin_amd/host/mbridge.c
 HOST_HDR = $(wildcard marlin_amd/host/*.h) include/marlin_gpu.h
-ORC_SRC  = oracle/orc_squery.c oracle/orc_sort.c
+ORC_SRC  = oracle/orc_squery.c oracle/orc_sort.c oracle/orc_merge.c
 GPU_SRC  = $(wildcard marlin_amd/csrc/*.hip)
 GPU_HDR  = $(wildcard marlin_amd/csrc/*.h) include/marlin_gpu.h
 

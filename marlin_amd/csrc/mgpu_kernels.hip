@@ -2461,7 +2461,11 @@ void mgk_rank(hipStream_t st, const SqDev *sqs, const uint32_t *blob, uint32_t m
               uint32_t max_tab_slots, const uint2 *tile_list, const uint32_t *tile_count, uint32_t tile_cap,
               unsigned long long *pool, uint32_t *pool_used, uint64_t pool_cap) {
     if (max_tab_slots > MG_LDS_HASH) max_tab_slots = MG_LDS_HASH;
-    hipLaunchKernelGGL(k_rank_tile, dim3(worklist_grid(tile_cap)), dim3(MG_BLOCK), (size_t)max_tab_slots * sizeof(uint2), st,
+    // workgroups of the persistent grid: MGPU_RANK_GRID overrides the default (a tuning knob; any value >= 1 is correct)
+    static const uint32_t grid_env = [] { const char *e = getenv("MGPU_RANK_GRID"); long v = e ? atol(e) : 0; return (uint32_t)(v > 0 && v <= 65535 ? v : 0); }();
+    uint32_t grid = grid_env ? grid_env : worklist_grid(tile_cap);
+    if (grid > tile_cap && tile_cap) grid = tile_cap;
+    hipLaunchKernelGGL(k_rank_tile, dim3(grid), dim3(MG_BLOCK), (size_t)max_tab_slots * sizeof(uint2), st,
                        sqs, blob, tile_list, tile_count);
     uint32_t gy = (max_n + MG_BLOCK - 1) / MG_BLOCK;
     uint32_t cap = 4096 / nsq; if (cap < 4) cap = 4;

@@ -15,12 +15,13 @@ class GpuError(RuntimeError):
     pass
 
 
-def assemble(index, pq, sqres):
+def assemble(index, pq, sqres, form=None):
     """sqres: ctypes array of SqResult, one per shard.  Returns a dict shaped like the
-    reference's response (query.c:312-422) without the stored documents' bodies."""
+    reference's response (query.c:312-422) without the stored documents' bodies.
+    form: the merge function (default: the product's m_form_result; the test oracle passes its own restatement)."""
     lib = index.lib
     res = ffi.Result()
-    lib.m_form_result(pq.q, sqres, index.num_shards, C.byref(res))
+    (form or lib.m_form_result)(pq.q, sqres, index.num_shards, C.byref(res))
     q = pq.q.contents
     out = {"totalHits": res.total_hits, "numHits": res.num_hits, "page": q.page_num,
            "fullScan": bool(res.full_scan), "hits": [], "facets": {}, "ranks": []}

@@ -57,6 +57,10 @@ void     orc_bm_andnot(uint64_t *dst, const uint64_t *src, size_t words);
 uint64_t orc_bm_cardinality(const uint64_t *a, size_t words);
 void     orc_bm_from_list(uint64_t *dst, const uint32_t *docs, uint64_t n);
 
+/* the merge half of form_result (query.c:312-383, 39-92; metric-aggs.c merges), restated literally in orc_merge.c;
+ * out is freed with m_result_free */
+void orc_form_result(const m_query_t *q, m_sqresult_t *sq, int num_shards, m_result_t *out);
+
 /* seconds this thread spent inside mdict_lookup_term / mdict_lookup_exact since its last reset */
 double orc_lookup_time(int reset);
 

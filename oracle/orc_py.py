@@ -28,6 +28,8 @@ def load():
         lib.orc_bench_pool.restype = C.c_double
         lib.orc_bench_pool.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.POINTER(ffi.Query)), C.c_int, C.c_int,
                                        C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+        lib.orc_form_result.restype = None
+        lib.orc_form_result.argtypes = [C.POINTER(ffi.Query), C.POINTER(ffi.SqResult), C.c_int, C.POINTER(ffi.Result)]
         _lib = lib
     return _lib
 
@@ -50,7 +52,7 @@ def lookup_time(reset=False):
 def search(index, pq, flags=0):
     """the oracle's answer for one parsed query, assembled like the GPU path's"""
     outs = execute_raw(index, pq, flags)
-    r = assemble(index, pq, outs)
+    r = assemble(index, pq, outs, form=load().orc_form_result)       # the oracle's own merge (orc_merge.c), not the product's
     if flags:
         r["_shards"] = shard_results_to_py(index, pq, outs)
     for s in range(index.num_shards):

@@ -56,6 +56,11 @@ def datagen_index(rend=10000, seed=12345):
     return ix, fcount
 
 
+# merged facet lists compared / left out because a shard's tied tail differed (several shards only)
+COMPARED_MERGED_FACETS = [0]
+SKIPPED_MERGED_FACETS = [0]
+
+
 def compare_results(gpu, orc, ctx="", key_fields=RANK_FIELDS):
     """GPU result vs oracle result for one query (both assembled with capture flags 3).
 
@@ -108,11 +113,14 @@ def compare_results(gpu, orc, ctx="", key_fields=RANK_FIELDS):
     # differed in its tied tail.
     gf, of = facets_canonical(gpu), facets_canonical(orc)
     assert gf.keys() == of.keys(), ctx
-    names = list(gf.keys())
-    for n, k in enumerate(names):
-        fields = [f for f in exact_lists]
-        if len(gpu["_shards"]) > 1 and fields and not all(exact_lists.values()):
+    # field names appear in field order in the merged dict, field indices in the same order in the shard dicts
+    by_order = dict(zip(gf.keys(), sorted(exact_lists)))
+    for k in gf:
+        f = by_order.get(k)
+        if len(gpu["_shards"]) > 1 and f is not None and not exact_lists[f]:
+            SKIPPED_MERGED_FACETS[0] += 1                     # this field only; tools/fuzz_parity.py prints the count
             continue
+        COMPARED_MERGED_FACETS[0] += 1
         assert [c for c, _ in gf[k]] == [c for c, _ in of[k]], (ctx, k)
         if gf[k]:
             cut = gf[k][-1][0]

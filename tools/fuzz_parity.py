@@ -9,6 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from marlin_amd import GpuEngine, Index, QueryError, ffi
 from oracle import orc_py
+import util
 from util import RANK_FIELDS, compare_results, datagen_index
 
 
@@ -188,6 +189,8 @@ def main(rounds=200, seed=1):
     n3, b3 = run(ix3, e3, custom_queries(rng, rounds), "custom")
     e3.close(); ix3.close()
     print("fuzz: %d + %d + %d queries, %d + %d + %d mismatches" % (n1, n2, n3, b1, b2, b3))
+    print("merged facet lists: %d compared, %d left out because a shard's tied tail differed (DESIGN.md, ties)"
+          % (util.COMPARED_MERGED_FACETS[0], util.SKIPPED_MERGED_FACETS[0]))
     return b1 + b2 + b3
 
 
