@@ -288,6 +288,23 @@ def main():
             eng.free_prepared(pr)
         lat_dev.sort()
 
+    # ---- the same batches with the term lookup inside the loop (typo walks on the device, row f-1): one batch at a time,
+    # prepare (device lookups + plan building on the host's threads) -> execute -> merge
+    qps_lookup = None
+    if world == 1 and not args.no_latency:
+        nb = 6
+        qarrs = [(C.POINTER(ffi.Query) * B)(*[p.q for p in batch_queries(j)]) for j in range(nb)]
+        for j in range(nb + 1):
+            if j == 1:
+                torch.cuda.synchronize(); t0b = time.perf_counter()         # batch 0 warms the lookup buffers
+            pqs_j = batch_queries(j % nb)
+            pr = eng.prepare(pqs_j, device_lookup=True)
+            o = eng.execute_prepared(pr)
+            lib.m_form_result_batch(qarrs[j % nb], o, B, local, None, 0)
+            eng.free_raw(o)
+            eng.free_prepared(pr)
+        qps_lookup = nb * B / (time.perf_counter() - t0b)
+
     # ---- roofline of the dominant kernel stage: HIP events on the launch stream, profiled batches
     roof = None
     stage_tab = {}
@@ -374,6 +391,7 @@ def main():
                            "with_term_lookup_p99": round(lat_full[int(len(lat_full) * 0.99)], 3),
                            "with_device_term_lookup_p50": round(lat_dev[len(lat_dev) // 2], 3),
                            "with_device_term_lookup_p99": round(lat_dev[int(len(lat_dev) * 0.99)], 3)} if lat else None,
+            "with_device_term_lookup_qps": round(qps_lookup, 1) if qps_lookup else None,
             "stages": stage_tab,
             "host_ms_per_step": {k: round(v, 3) for k, v in host_acc.items()},
             "setup_s": {"build_shards": round(t_build, 1), "mirror": round(t_mirror, 1), "term_lookup": round(t_prepare, 2),
