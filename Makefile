@@ -5,7 +5,7 @@ HIPCC   ?= /opt/rocm/bin/hipcc
 CFLAGS  ?= -O2 -g -std=gnu11 -fPIC -Wall -Wextra -Wno-unused-parameter
 REF     ?= /root/reference
 
-HOST_SRC = marlin_amd/host/mdict.c marlin_amd/host/mshard.c marlin_amd/host/manalyzer.c \
+HOST_SRC = marlin_amd/host/mdict.c marlin_amd/host/mshard.c marlin_amd/host/manalyzer.c marlin_amd/host/mhighlight.c \
            marlin_amd/host/mquery.c marlin_amd/host/mplan.c marlin_amd/host/mbridge.c
 HOST_HDR = $(wildcard marlin_amd/host/*.h) include/marlin_gpu.h
 ORC_SRC  = oracle/orc_squery.c oracle/orc_sort.c oracle/orc_merge.c

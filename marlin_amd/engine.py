@@ -8,7 +8,7 @@ There is no CPU fallback: if libmarlin_gpu.so or a GPU is missing, construction 
 """
 import ctypes as C
 
-from . import ffi
+from . import ffi, hits
 
 
 class GpuError(RuntimeError):
@@ -34,7 +34,7 @@ def assemble(index, pq, sqres, form=None):
             hit = {"_docid": r.docid, "_shard": r.shard_id}
             docs = index.docs[r.shard_id] if index.docs else None
             if docs:
-                hit.update(docs[r.docid - 1])
+                hit.update(hits.materialize(lib, pq, docs[r.docid - 1]))     # getFields + highlight (row f-4)
             if pq.explain:
                 hit["_explain"] = {k: rec[k] for k in ("typos", "proximity", "position", "exact", "field")}
             out["hits"].append(hit)

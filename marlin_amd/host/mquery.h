@@ -51,6 +51,11 @@ typedef struct m_result {
 void m_form_result(const m_query_t *q, m_sqresult_t *sq, int num_shards, m_result_t *out);
 void m_result_free(m_result_t *r);
 
+/* highlight (highlight.c:215-345): `str` with the leading part of every token that matches a query term wrapped in
+ * <mark> </mark>, or NULL when nothing matches; snip_num_words as in the reference (its callers pass 0).  mhighlight.c */
+char *m_highlight(const char *str, const m_query_t *q, int snip_num_words);
+void  m_highlight_free(char *s);
+
 /* __sort_lt (sort.c:46-100) */
 bool m_rank_lt(const m_docrank_t *a, const m_docrank_t *b, const int *rules);
 /* total order used wherever this implementation must break the reference's ties */

@@ -9,7 +9,7 @@ jansson on the host; none of it is on the GPU path.
 import ctypes as C
 import zlib
 
-from . import ffi
+from . import ffi, hits
 
 F_STRING, F_STRLIST, F_NUMBER, F_NUMLIST, F_BOOLEAN, F_NULL = "string", "strlist", "number", "numlist", "boolean", "null"
 
@@ -208,6 +208,10 @@ class ParsedQuery:
             merged = dict(index.settings)
             merged.update(jq)
             self._settings(q, merged)
+            try:
+                self.hit_cfg = hits.hit_settings(merged)          # getFields / highlightFields / highlightSource
+            except ValueError as e:
+                raise QueryError(str(e))
             jf = jq.get("filter")
             if jf:
                 f = self._parse_filter(jf)
