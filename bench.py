@@ -131,7 +131,8 @@ def main():
     # keeps the same size: the corpus is fixed, the query stream is not: per-GPU work per step is constant (weak scaling)
     B = args.batch * world
     S = max(1, args.sub)
-    nq_pool = max(256, 2 * B)            # (the same 256 queries as round 1: the mean hit count of a sample moves the rate)
+    nq_pool = 256                        # the same 256 queries at every N (and as in round 1): the mean hit count of a
+                                         # sample moves the rate, so a larger batch cycles through them instead of drawing more
     pool = [ix.query(j) for j in make_queries(lib, nq_pool)]
     K_TOP, NF, FMAX, NAGG = 10, 2, 20, 0
     slot_b = lib.m_slot_bytes(K_TOP, NF, FMAX, NAGG)
