@@ -1,8 +1,9 @@
 /* mplan.h -- host side of the GPU shard query: mirror export and plan lowering.
  *
  * This is the part of execute_squery that stays on the CPU (squery.c:144-167 lookup_terms:
- * trie lookups, twid -> wid expansion, wid -> distance maps; filter-tree leaves resolved to
- * posting ids / key ranges) and hands a flat mgpu_plan_t to libmarlin_gpu.so.  It never
+ * exact trie descents, twid -> wid expansion, wid -> distance maps; filter-tree leaves resolved to
+ * posting ids / key ranges; the typo walks go to the device with msq_prepare_batch_dev) and hands a flat
+ * mgpu_plan_t to libmarlin_gpu.so.  It never
  * touches the oracle; if the GPU library reports an error the error is returned.
  */
 #ifndef MARLIN_AMD_MPLAN_H
@@ -42,9 +43,9 @@ typedef struct mplan {
     int fops_cap;
 } mplan_t;
 
-/* lookup_terms + process_termresult + filter leaf resolution for one shard.
- * returns 0, or MGPU_E_UNSUPPORTED when the query would take the fast-rank path
- * (docrank.c:571) -- decided after execution from num_hits, see msq_execute. */
+/* lookup_terms + process_termresult + filter leaf resolution for one shard.  Whether the squery is then ranked on a
+ * sample (fast-rank, docrank.c:571) is decided on the device from the hit count; the plan carries full_scan and
+ * full_scan_threshold for it. */
 int  mplan_build(const mmirror_t *m, const m_query_t *q, int capture, mplan_t *out);
 /* the same after the trie walk: tr[t] = dtrie_lookup_term's result per term (wordids get the words under a twid
  * added), exact_wid[i] = dtrie_lookup_exact's result per query word; q->terms / q->words are not read */
