@@ -7,6 +7,7 @@
  * with the reference's calling convention (query.c:446 threadpool job, query.c:461 inline call, query.c:468-470
  * free), and two set-up calls a maintainer adds where a shard is opened / after a bulk commit (sindex.c:246):
  *      int  mgpu_shim_attach_shard(struct shard *s, int device);   -- mirror the shard's LMDB into HBM
+ *      int  mgpu_shim_refresh_shard(struct shard *s);              -- after a commit: rebuild + swap if LMDB moved on
  *      void mgpu_shim_detach_shard(struct shard *s);
  * What stays on the host is what north_star keeps there: the exact descents of the dtrie (twid / no-typo lookups,
  * dtrie_lookup_exact), LMDB, filter and agg parsing.  The typo walk of dtrie_lookup_term (dtrie.c:763-791) runs on the
@@ -53,7 +54,7 @@ _Static_assert(R_MAX + 1 <= M_MAX_RULES, "rank_rule length");
 /* ------------------------------------------------------------------ attached mirrors */
 #define SHIM_MAX_SHARDS 256
 #define SHIM_CTX_PER_DEVICE 16
-struct shim_entry { struct shard *shard; mshard_t *src; mmirror_t *mirror; int device; };
+struct shim_entry { struct shard *shard; mshard_t *src; mmirror_t *mirror; int device; size_t txnid; };
 static struct shim_entry g_shards[SHIM_MAX_SHARDS];
 static pthread_rwlock_t g_shards_lock = PTHREAD_RWLOCK_INITIALIZER;
 /* execution contexts (one HIP stream + workspace each), handed out per call: execute_squery runs on search_pool
@@ -189,6 +190,7 @@ int mgpu_shim_attach_shard(struct shard *s, int device) {
     if (!map || device < 0 || device >= 64) return MGPU_E_ARG;
     MDB_txn *txn;
     if (mdb_txn_begin(si->env, NULL, MDB_RDONLY, &txn) != 0) return MGPU_E_ARG;
+    const size_t snap_txnid = mdb_txn_id(txn);                      /* the commit this snapshot reflects */
     mbridge_t *mb = mbr_new(map->num_numbers, map->num_bools, map->num_facets,
                             si->trie->meta->word_count, si->trie->meta->tword_count);
     int rc = mb ? 0 : MGPU_E_LIMIT;
@@ -246,7 +248,7 @@ int mgpu_shim_attach_shard(struct shard *s, int device) {
     rc = MGPU_E_LIMIT;
     for (int i = 0; i < SHIM_MAX_SHARDS; i++) {
         if (g_shards[i].shard) continue;
-        g_shards[i] = (struct shim_entry){ s, src, mirror, device };
+        g_shards[i] = (struct shim_entry){ s, src, mirror, device, snap_txnid };
         rc = 0;
         break;
     }
@@ -449,6 +451,23 @@ void execute_squery(void *w) {
     mplan_free(&plan);
     mq_free(mq);
     finish(sq);
+}
+
+/* Row f-2, the part that exists: refresh keyed on the commit.  Call where a bulk write ends (sindex.c:246).  When the
+ * environment's last committed transaction is newer than the one the mirror was built from, a new mirror is built from
+ * a fresh read snapshot NEXT to the live one -- queries keep running on the old mirror -- and swapped in under the
+ * table's write lock (mgpu_shim_attach_shard); otherwise nothing happens.  The rebuild is complete, not incremental.
+ * Returns 0 (up to date or refreshed), 1 when the shard was never attached, or an MGPU_E_* code. */
+int mgpu_shim_refresh_shard(struct shard *s) {
+    int device = -1; size_t have = 0;
+    pthread_rwlock_rdlock(&g_shards_lock);
+    for (int i = 0; i < SHIM_MAX_SHARDS; i++) if (g_shards[i].shard == s) { device = g_shards[i].device; have = g_shards[i].txnid; break; }
+    pthread_rwlock_unlock(&g_shards_lock);
+    if (device < 0) return 1;
+    MDB_envinfo info;
+    if (mdb_env_info(s->sindex->env, &info) != 0) return MGPU_E_ARG;
+    if (info.me_last_txnid <= have) return 0;
+    return mgpu_shim_attach_shard(s, device);
 }
 
 void sqresult_free(struct query *q, struct squery_result *sqres) {

@@ -26,10 +26,11 @@ def test_shim_compiles_against_reference_headers_and_exports_the_seam():
     assert "warning" not in r.stdout
     nm = subprocess.run(["nm", SHIM_OBJ], stdout=subprocess.PIPE, text=True).stdout
     defined = {l.split()[-1] for l in nm.splitlines() if " T " in l}
-    assert {"execute_squery", "sqresult_free", "mgpu_shim_attach_shard", "mgpu_shim_detach_shard"} <= defined
+    assert {"execute_squery", "sqresult_free", "mgpu_shim_attach_shard", "mgpu_shim_detach_shard", "mgpu_shim_refresh_shard"} <= defined
     undefined = {l.split()[-1] for l in nm.splitlines() if " U " in l}
     # host work that stays with the reference, GPU work that goes through the host library; no oracle, no CPU ranking
-    assert {"dtrie_lookup_term", "dtrie_lookup_exact", "mplan_from_terms", "msq_execute_plan", "mmirror_create"} <= undefined
+    assert {"dtrie_lookup_term", "dtrie_lookup_exact", "mplan_from_terms", "msq_execute_plan", "mmirror_create",
+            "mgpu_dict_create", "mgpu_lookup_terms"} <= undefined
     assert not {u for u in undefined if u.startswith("orc_") or u in ("perform_ranking", "filter_apply", "rank_sort")}
 
 
