@@ -126,3 +126,36 @@ def test_scan_equals_trie_walk_datagen_and_queries():
             compare_results(g, orc_py.search(ix, pq, flags=3), ctx=pq.jq)
     finally:
         eng.close(); ix.close()
+
+
+def test_scan_equals_trie_walk_on_a_zipf_vocabulary():
+    """a 20000-word vocabulary of the bench generator (words of 4-10 letters): typo'd words, transpositions, two-word and
+    three-word concatenations (the reference's odd terms, up to two edits), prefixes of every length"""
+    lib = ffi.load()
+    V, S = 20000, 9
+    shards = [lib.msynth_zipf(60000, V, 500, S, s, 2) for s in range(2)]
+    ix = Index.from_shards({}, shards, ["str"], ["num", "price"], ["flag"], ["cat", "hc"])
+    eng = GpuEngine(ix)
+    try:
+        rng = random.Random(3)
+        buf = C.create_string_buffer(16)
+
+        def word(r):
+            lib.msynth_zipf_word(V, S, r, buf)
+            return buf.value.decode()
+        terms = set()
+        for _ in range(40):
+            w = word(rng.randrange(0, 3000))
+            p = rng.randrange(len(w))
+            terms.add(w[:p] + rng.choice("abcdefghijklmnopqrstuvwxyz") + w[p + 1:])          # substitution
+            if len(w) > 4:
+                i = rng.randrange(len(w) - 1)
+                terms.add(w[:i] + w[i + 1] + w[i] + w[i + 2:])                               # transposition
+                terms.add(w[:p] + w[p + 1:])                                                 # deletion
+            terms.add(w + word(rng.randrange(0, 200)))                                       # two words run together
+            terms.add(w[:rng.randrange(4, len(w) + 1)])                                      # a prefix
+        terms.add(word(1) + word(2) + word(3))
+        n = check_terms(ix, eng, sorted(terms))
+        assert n > 200
+    finally:
+        eng.close(); ix.close()
