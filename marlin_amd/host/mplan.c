@@ -440,6 +440,11 @@ int msq_prepare_batch_dev(mgpu_ctx_t *ctx, mmirror_t *const *mirrors, int num_sh
         }
     }
     int rc = 0;
+    static int trace = -1;
+    if (trace < 0) trace = getenv("MSQ_PREP_TRACE") != NULL;
+    struct timespec ts0, ts1, ts2;
+    clock_gettime(CLOCK_MONOTONIC, &ts0);
+    size_t nhits_total = 0;
     /* at most 65535 lookups per call */
     for (size_t lo = 0; lo < nl && !rc; lo += 65535) {
         const int cnt = (int)(nl - lo < 65535 ? nl - lo : 65535);
@@ -452,10 +457,17 @@ int msq_prepare_batch_dev(mgpu_ctx_t *ctx, mmirror_t *const *mirrors, int num_sh
             /* add_wordid_to_result (dtrie.c:633-640): least distance */
             if ((int)hits[h].dist < m_u32map_get(&tr->wordids, hits[h].wid, 0xFF)) m_u32map_set(&tr->wordids, hits[h].wid, (int32_t)hits[h].dist);
         }
+        nhits_total += nh;
         mgpu_term_hits_free(hits);
     }
     free(lk); free(slot);
+    clock_gettime(CLOCK_MONOTONIC, &ts1);
     if (!rc) rc = prepare_common(mirrors, num_shards, queries, nq, capture, pre, have, out);
+    if (trace) {
+        clock_gettime(CLOCK_MONOTONIC, &ts2);
+        fprintf(stderr, "[prepare_dev] %zu lookups, %zu hits: device scan + maps %.3f ms, plans %.3f ms\n", nl, nhits_total,
+                (ts1.tv_sec - ts0.tv_sec) * 1e3 + (ts1.tv_nsec - ts0.tv_nsec) * 1e-6, (ts2.tv_sec - ts1.tv_sec) * 1e3 + (ts2.tv_nsec - ts1.tv_nsec) * 1e-6);
+    }
     for (size_t i = 0; i < (size_t)n * M_MAX_QTERMS; i++) if (pre[i].wordids.cap) m_termresult_free(&pre[i]);
     free(pre); free(have);
     return rc;
