@@ -213,11 +213,11 @@ class ParsedQuery:
             except ValueError as e:
                 raise QueryError(str(e))
             jf = jq.get("filter")
-            if jf:
+            if isinstance(jf, dict) and jf:          # index.c:1091-1093: anything but a non-empty object is no filter
                 f = self._parse_filter(jf)
                 q.filter = f
             ja = jq.get("aggs")
-            if ja:
+            if isinstance(ja, dict) and ja:          # index.c:1107-1109, same rule
                 self._parse_aggs(ja)
             page = jq.get("page")
             if isinstance(page, int) and not isinstance(page, bool):
