@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="multi-rank rehearsal on ONE GPU: gloo collectives on host tensors, every rank on cuda:0")
     ap.add_argument("--no-latency", action="store_true", help="skip the 200 single-query latency probes (cleaner kernel profiles)")
+    ap.add_argument("--distinct", type=int, default=4096, help="distinct queries the stream cycles through")
     ap.add_argument("--inflight", type=int, default=8, help="batches kept in flight per GPU (= contexts; one host thread per two contexts on one GPU)")
     args = ap.parse_args()
 
@@ -131,8 +132,9 @@ def main():
     # keeps the same size: the corpus is fixed, the query stream is not: per-GPU work per step is constant (weak scaling)
     B = args.batch * world
     S = max(1, args.sub)
-    nq_pool = 256                        # the same 256 queries at every N (and as in round 1): the mean hit count of a
-                                         # sample moves the rate, so a larger batch cycles through them instead of drawing more
+    nq_pool = max(B, args.distinct // B * B)   # distinct queries of the stream (rounds 1 and 2 cycled through the first 256
+                                         # of the same generator; the mean hit count of a sample moves the rate: 18k there,
+                                         # 28k over 4096)
     pool = [ix.query(j) for j in make_queries(lib, nq_pool)]
     K_TOP, NF, FMAX, NAGG = 10, 2, 20, 0
     slot_b = lib.m_slot_bytes(K_TOP, NF, FMAX, NAGG)
@@ -146,12 +148,17 @@ def main():
         gather = ShardGather(lib, dist, world, rank, B, local, K_TOP, NF, FMAX, NAGG,
                              device=None if args.rehearse_gloo else "cuda:%d" % local_rank, nslots=max(1, args.inflight))
 
-    # Term lookup (the dtrie walk of lookup_terms) is outside the north-star path ("per-shard
-    # query execution after term lookup"): resolve it once per distinct batch, before timing.
+    # Term lookup (the DICTIONARY half of lookup_terms: dtrie_lookup_term / dtrie_lookup_exact) is outside the north-star
+    # path ("per-shard query execution after term lookup"): resolved once per distinct batch, before timing, with the
+    # typo walks on the device (row f-1).  Everything after it -- process_termresult (posting selection, all_wordids, zero-typo
+    # sets), exact wids, filter leaves: msq_plan_resolved -- is built INSIDE the timed loop, per batch, by the pipeline's threads.
     t0 = time.time()
     nbatches = max(1, nq_pool // B)
-    prepared = [eng.prepare(batch_queries(j)) for j in range(nbatches)]
+    resolved = [eng.resolve(batch_queries(j), device_lookup=True) for j in range(nbatches)]
     t_prepare = time.time() - t0
+    # prepared batches (plans built ahead) only for the N > 1 loop, the stage profile and the replay line
+    nprep = nbatches if world > 1 else min(nbatches, 8)
+    prepared = [eng.plan_resolved(resolved[j]) for j in range(nprep)]
 
     F = max(1, args.inflight)
     order = threading.Condition()
@@ -163,7 +170,7 @@ def main():
         """one batch: GPU execute_squery for every (query, shard) + the form_result merge.  With
         --gpus > 1 the cross-rank gather of step `seq` waits for its turn, so every rank issues its
         collectives in the same order whatever the host threads do."""
-        prep = prepared[step % nbatches]
+        prep = prepared[step % nprep]
         pqs = prep[2]
         outs = eng.execute_prepared(prep, slot)
         hits = 0
@@ -184,7 +191,7 @@ def main():
             # every rank merges its own share of the batch's queries (the gather delivered all slots everywhere)
             mine = gather.my_queries()
             if mine:
-                key = step % nbatches                    # the pointer array of a prepared batch is built once
+                key = step % nprep                       # the pointer array of a prepared batch is built once
                 if key not in qsub_cache:
                     qsub_cache[key] = (C.POINTER(ffi.Query) * len(mine))(*[pqs[i].q for i in mine])
                 hits = lib.m_form_result_batch(qsub_cache[key], sq, len(mine), TOTAL_SHARDS, None, 0)
@@ -192,11 +199,15 @@ def main():
         eng.free_raw(outs)
         return hits
 
+    plan_ms = [0.0]
+
     def run_steps(first, count):
         """`count` steps with up to F batches in flight (one host thread and one context each)"""
         if world == 1:
             # one GPU: the whole loop is native (host threads, contexts, execute + merge: mplan.c)
-            return eng.run_pipeline(prepared, first, count, F)
+            hits, pms = eng.run_pipeline_resolved(resolved, first, count, F)
+            plan_ms[0] = pms
+            return hits
         gather_turn[0] = 0
         hits = [0] * F
         err = []
@@ -232,10 +243,10 @@ def main():
     # here too and stay parked between runs: nothing of this is left for the timed region.
     t0 = time.time()
     if world == 1:
-        eng.warm_pipeline(prepared, F)
+        eng.warm_pipeline_resolved(resolved, F)
     else:
         for slot in range(F):
-            for j in range(nbatches):
+            for j in range(nprep):
                 eng.free_raw(eng.execute_prepared(prepared[j], slot))
         gather_turn[0] = 0
         for slot in range(F):
@@ -258,6 +269,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     qps = args.steps * S * B / dt
+    plan_ms_batch = plan_ms[0] / max(1, args.steps * S)
+
+    # the line rounds 1 and 2 reported: the first 256 queries as two batches prepared ahead and replayed (no plan building
+    # in the loop) -- kept for continuity only
+    qps_replay = None
+    if world == 1 and nprep >= 2 and B == 128:
+        eng.run_pipeline(prepared[:2], 0, 2 * S, F)
+        torch.cuda.synchronize(); t0r = time.perf_counter()
+        eng.run_pipeline(prepared[:2], 0, 10 * S, F)
+        qps_replay = 10 * S * B / (time.perf_counter() - t0r)
 
     # ---- single-query latency (batch of 1, unloaded), p50 / p99 over 200 queries
     lat, lat_full, lat_dev = [], [], []
@@ -312,9 +333,9 @@ def main():
     eng.set_profiling(True)
     acc = {}
     host_acc = {}
-    nprof = 5
+    nprof = min(8, nprep) if nprep > 2 else 5
     for s in range(nprof):
-        o = eng.execute_prepared(prepared[s % nbatches])
+        o = eng.execute_prepared(prepared[s % nprep])
         eng.free_raw(o)
         tm = eng.timing()
         for hk, hv in tm["host_ms"].items():
@@ -385,7 +406,12 @@ def main():
             "config": {"workload": "configs[2]: %d docs Zipf corpus, %d shards, 3-word typo+prefix query, 2 facet fields, "
                                    "rankBy num desc, top-10, fullScan" % (args.docs, TOTAL_SHARDS),
                        "queries_per_step": B * S, "queries_per_device_batch": B, "device_batches_per_step": S, "batches_in_flight": F, "shards_per_gpu": local, "vocab": VOCAB,
-                       "mean_hits_per_query": round(total_hits / max(1, args.steps * S * B), 1)},
+                       "mean_hits_per_query": round(total_hits / max(1, args.steps * S * B), 1),
+                       "distinct_queries": nq_pool, "plans_in_timed_region": world == 1,
+                       "timed_region": "per batch: process_termresult for 128 queries x 8 shards (msq_plan_resolved) + plan lowering + "
+                                       "upload + kernels + download + decode + form_result; dictionary lookups resolved before"},
+            "plan_build_ms_per_batch": round(plan_ms_batch, 3),
+            "replay_256_prepared_qps": round(qps_replay, 1) if qps_replay else None,
             "roofline": roof, "cpu_baseline": cpu,
             "latency_ms": {"p50": round(lat[len(lat) // 2], 3), "p99": round(lat[int(len(lat) * 0.99)], 3),
                            "with_term_lookup_p50": round(lat_full[len(lat_full) // 2], 3),
@@ -402,6 +428,8 @@ def main():
         print(json.dumps(line), flush=True)
     for pr in prepared:
         eng.free_prepared(pr)
+    for r in resolved:
+        eng.free_resolved(r)
     eng.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -200,8 +200,8 @@ class GpuEngine:
             raise GpuError("msq_pipeline_warm: %d %s" % (rc, self.lib.msq_pipeline_error(pipe).decode()))
 
     def run_pipeline(self, preps, first, count, nthreads=None):
-        """`count` steps of the native serving loop (mplan.c:msq_pipeline_run): nthreads host threads, one
-        context each, step i = execute_prepared + form_result of preps[(first + i) % len(preps)];
+        """`count` steps of the native serving loop (mplan.c:msq_pipeline_run) over `nthreads` contexts (one host
+        thread per two contexts), step i = execute_prepared + form_result of preps[(first + i) % len(preps)];
         returns the summed totalHits"""
         pipe = self._pipeline(nthreads)
         parr = (C.c_void_p * len(preps))(*[p[0] for p in preps])
@@ -210,6 +210,51 @@ class GpuEngine:
         if rc:
             raise GpuError("msq_pipeline_run: %d %s" % (rc, self.lib.msq_pipeline_error(pipe).decode()))
         return hits.value
+
+    def resolve(self, pqs, device_lookup=False):
+        """the DICTIONARY half of lookup_terms for a batch (msq_resolve_batch): dtrie_lookup_term per term and shard,
+        dtrie_lookup_exact per word; device_lookup runs the typo walks on the GPU (row f-1).  Returns a handle for
+        run_pipeline_resolved / plan_resolved; the parsed queries must stay alive as long as the handle."""
+        ns = self.index.num_shards
+        nq = len(pqs)
+        qarr = (C.POINTER(ffi.Query) * nq)(*[p.q for p in pqs])
+        h = C.c_void_p()
+        rc = self.lib.msq_resolve_batch(self.ctx if device_lookup else None, self._marr, ns, qarr, nq, C.byref(h))
+        if rc:
+            raise GpuError("msq_resolve_batch: %d %s" % (rc, self.lib.mgpu_last_error().decode()))
+        return (h, nq, pqs, qarr)
+
+    def free_resolved(self, res):
+        self.lib.msq_resolved_free(res[0])
+
+    def plan_resolved(self, res, capture=0):
+        """everything of lookup_terms after the dictionary (process_termresult, exact wids, filter leaves) for a
+        resolved batch; returns a prepared handle like prepare()"""
+        h = C.c_void_p(self.lib.msq_prepared_new())
+        rc = self.lib.msq_plan_resolved(res[0], capture, h)
+        if rc:
+            self.lib.msq_prepared_free(h)
+            raise GpuError("msq_plan_resolved: %d %s" % (rc, self.lib.mgpu_last_error().decode()))
+        return (h, res[1], res[2])
+
+    def warm_pipeline_resolved(self, ress, nthreads=None):
+        pipe = self._pipeline(nthreads)
+        parr = (C.c_void_p * len(ress))(*[r[0] for r in ress])
+        rc = self.lib.msq_pipeline_warm_resolved(pipe, parr, len(ress))
+        if rc:
+            raise GpuError("msq_pipeline_warm_resolved: %d %s" % (rc, self.lib.msq_pipeline_error(pipe).decode()))
+
+    def run_pipeline_resolved(self, ress, first, count, nthreads=None):
+        """the native serving loop with the plans built inside it: step i = msq_plan_resolved + mgpu_execute_begin /
+        _end + form_result of ress[(first + i) % len(ress)], all in the pipeline's own threads (two contexts per
+        thread).  Returns (summed totalHits, host ms spent building plans summed over the threads)."""
+        pipe = self._pipeline(nthreads)
+        parr = (C.c_void_p * len(ress))(*[r[0] for r in ress])
+        hits = C.c_long(0)
+        rc = self.lib.msq_pipeline_run_resolved(pipe, parr, len(ress), first, count, C.byref(hits))
+        if rc:
+            raise GpuError("msq_pipeline_run_resolved: %d %s" % (rc, self.lib.msq_pipeline_error(pipe).decode()))
+        return hits.value, self.lib.msq_pipeline_plan_ms(pipe)
 
     def free_prepared(self, prep):
         self.lib.msq_prepared_free(prep[0])

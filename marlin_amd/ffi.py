@@ -112,6 +112,29 @@ class TermHit(C.Structure):
     _fields_ = [("lookup", C.c_uint32), ("wid", C.c_uint32), ("dist", C.c_uint32)]
 
 
+class WidEntry(C.Structure):
+    """mgpu_wid_entry_t"""
+    _fields_ = [("wid", C.c_uint32), ("dist", C.c_uint8), ("mterm", C.c_uint8), ("exact_mask", C.c_uint16)]
+
+
+class Fop(C.Structure):
+    """mgpu_fop_t"""
+    _fields_ = [("op", C.c_int32), ("a", C.c_int32), ("lo", C.c_uint64), ("hi", C.c_uint64)]
+
+
+class Plan(C.Structure):
+    """mgpu_plan_t (include/marlin_gpu.h)"""
+    _fields_ = [("num_terms", C.c_int32), ("num_words", C.c_int32), ("term_npost", C.c_uint32 * 32),
+                ("term_post", C.POINTER(C.c_uint32) * 32), ("term_nzero", C.c_uint32 * 32), ("exact_present", C.c_uint16),
+                ("num_wids", C.c_uint32), ("wids", C.POINTER(WidEntry)),
+                ("has_filter", C.c_int32), ("filter_null", C.c_int32), ("num_fops", C.c_int32), ("fops", C.POINTER(Fop)),
+                ("hits_per_page", C.c_int32), ("page_num", C.c_int32), ("max_facet_results", C.c_int32),
+                ("facet_enabled", C.c_uint32), ("rank_by", C.c_int32), ("rank_asc", C.c_int32),
+                ("rules", C.c_int32 * M_MAX_RULES), ("full_scan", C.c_int32), ("full_scan_threshold", C.c_uint32),
+                ("facet_pid_base", C.c_uint32 * M_MAX_FIELDS), ("num_aggs", C.c_int32),
+                ("agg_type", C.c_int32 * M_MAX_AGGS), ("agg_field", C.c_int32 * M_MAX_AGGS), ("capture", C.c_int32)]
+
+
 class ShardStruct(C.Structure):
     """leading fields of mshard_t that Python reads directly"""
     _fields_ = [("max_docid", C.c_uint32), ("num_strings", C.c_int), ("num_numbers", C.c_int),
@@ -251,6 +274,18 @@ def load():
         "msq_pipeline_warm": (ci, [vp, C.POINTER(vp), ci]),
         "msq_pipeline_run": (ci, [vp, C.POINTER(vp), ci, ci, ci, C.POINTER(C.c_long)]),
         "msq_pipeline_error": (C.c_char_p, [vp]),
+        "mmirror_scheme": (vp, [vp]),
+        "msq_resolve_batch": (ci, [vp, C.POINTER(vp), ci, C.POINTER(C.POINTER(Query)), ci, C.POINTER(vp)]),
+        "msq_resolved_free": (None, [vp]),
+        "msq_resolved_count": (ci, [vp]),
+        "msq_prepared_new": (vp, []),
+        "msq_prepared_plan": (C.POINTER(Plan), [vp, ci]),
+        "msq_resolved_term": (cu, [vp, ci, ci, C.POINTER(cu), C.POINTER(C.POINTER(cu)), C.POINTER(C.POINTER(C.c_uint8))]),
+        "msq_resolved_exact": (cu, [vp, ci, ci]),
+        "msq_plan_resolved": (ci, [vp, ci, vp]),
+        "msq_pipeline_warm_resolved": (ci, [vp, C.POINTER(vp), ci]),
+        "msq_pipeline_run_resolved": (ci, [vp, C.POINTER(vp), ci, ci, ci, C.POINTER(C.c_long)]),
+        "msq_pipeline_plan_ms": (cd, [vp]),
         "msq_pipeline_destroy": (None, [vp]),
         # GPU C ABI (include/marlin_gpu.h), reached through the same process image
         "mgpu_last_error": (C.c_char_p, []),
@@ -286,7 +321,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    expect = [DocRank, FacetCount, Agg, QueryCfg, Query, SqResult, Result, Filter, Word, Term, ShardFull]
+    expect = [DocRank, FacetCount, Agg, QueryCfg, Query, SqResult, Result, Filter, Word, Term, ShardFull, Plan]
     for i, st in enumerate(expect):
         if lib.m_sizeof(i) != C.sizeof(st):
             raise RuntimeError("ctypes mirror of %s is %d bytes, library says %d"

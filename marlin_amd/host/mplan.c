@@ -8,14 +8,24 @@
 #include <time.h>
 
 /* ------------------------------------------------------------------ mirror export */
-int mmirror_create(const mshard_t *s, int device, mmirror_t **out) {
+/* the posting-id scheme alone (no device): what plan building needs of a mirror */
+mmirror_t *mmirror_scheme(const mshard_t *s) {
     mmirror_t *m = calloc(1, sizeof(*m));
-    m->s = s; m->device = device;
+    if (!m) return NULL;
+    m->s = s; m->device = -1;
     m->W = s->word_count; m->T = s->tword_count;
     uint32_t pid = 1 + m->W + m->T;
     for (int f = 0; f < s->num_facets; f++) { m->fbase[f] = pid; pid += s->nfid[f]; }
     m->bbase = pid; pid += 2u * (uint32_t)s->num_bools;
     m->num_postings = pid;
+    return m;
+}
+
+int mmirror_create(const mshard_t *s, int device, mmirror_t **out) {
+    mmirror_t *m = mmirror_scheme(s);
+    if (!m) return MGPU_E_LIMIT;
+    m->device = device;
+    const uint32_t pid = m->num_postings;
 
     uint64_t total = s->has_used ? s->used_n : s->max_docid;
     total += s->wp_off[m->W + 1] + s->tp_off[m->T + 1];
@@ -83,22 +93,95 @@ void mmirror_destroy(mmirror_t *m) {
     free(m);
 }
 
+/* ------------------------------------------------------------------ arena
+ * Everything a batch of plans points to (posting-id lists, wid tables, filter programs, the plan array itself) comes out
+ * of one bump allocator that its owner resets between batches: no malloc per term or per plan.  Blocks never move, so
+ * pointers stay valid until the reset; a reset that finds several blocks replaces them by one of their total size.
+ * The arena also owns the scratch wid table a plan is built with (all_wordids of squery.c:100-105): generation-stamped
+ * slots, never cleared. */
+typedef struct m_ablk { struct m_ablk *next; size_t cap, used; } m_ablk_t;
+struct m_arena {
+    m_ablk_t *head;
+    uint32_t *hk, *hv, *hg;      /* scratch table: key (wid), value (index into the plan's wid entries), generation */
+    uint32_t hcap, gen;
+};
+#define ABLK_HDR ((sizeof(m_ablk_t) + 15) & ~(size_t)15)
+
+m_arena_t *m_arena_new(void) { return calloc(1, sizeof(m_arena_t)); }
+
+static void *arena_alloc(m_arena_t *a, size_t bytes) {
+    bytes = (bytes + 15) & ~(size_t)15;
+    m_ablk_t *b = a->head;
+    if (!b || b->used + bytes > b->cap) {
+        size_t cap = b ? b->cap * 2 : (size_t)1 << 16;
+        if (cap < bytes) cap = bytes;
+        m_ablk_t *nb = malloc(ABLK_HDR + cap);
+        if (!nb) return NULL;
+        nb->next = b; nb->cap = cap; nb->used = 0;
+        a->head = b = nb;
+    }
+    void *p = (char *)b + ABLK_HDR + b->used;
+    b->used += bytes;
+    return p;
+}
+
+void m_arena_reset(m_arena_t *a) {
+    if (!a || !a->head) return;
+    if (!a->head->next) { a->head->used = 0; return; }
+    size_t total = 0;
+    for (m_ablk_t *b = a->head; b;) { m_ablk_t *n = b->next; total += b->cap; free(b); b = n; }
+    a->head = NULL;
+    m_ablk_t *nb = malloc(ABLK_HDR + total);
+    if (nb) { nb->next = NULL; nb->cap = total; nb->used = 0; a->head = nb; }
+}
+
+void m_arena_free(m_arena_t *a) {
+    if (!a) return;
+    for (m_ablk_t *b = a->head; b;) { m_ablk_t *n = b->next; free(b); b = n; }
+    free(a->hk); free(a->hv); free(a->hg);
+    free(a);
+}
+
+/* scratch table for one plan with at most `n` distinct keys */
+static int wt_begin(m_arena_t *a, uint32_t n) {
+    uint32_t need = 64;
+    while (need < 4 * n) need <<= 1;
+    if (need > a->hcap) {
+        free(a->hk); free(a->hv); free(a->hg);
+        a->hk = malloc(sizeof(uint32_t) * need); a->hv = malloc(sizeof(uint32_t) * need); a->hg = calloc(need, sizeof(uint32_t));
+        a->hcap = a->hk && a->hv && a->hg ? need : 0; a->gen = 0;
+        if (!a->hcap) return -1;
+    }
+    if (++a->gen == 0) { memset(a->hg, 0, sizeof(uint32_t) * a->hcap); a->gen = 1; }
+    return 0;
+}
+static inline uint32_t wt_mix(uint32_t h) { h ^= h >> 16; h *= 0x7feb352dU; h ^= h >> 15; return h; }
+/* slot of `wid`: *found says whether it is there; an absent key's slot is where it goes */
+static inline uint32_t wt_find(const m_arena_t *a, uint32_t wid, int *found) {
+    const uint32_t mask = a->hcap - 1;
+    for (uint32_t i = wt_mix(wid) & mask;; i = (i + 1) & mask) {
+        if (a->hg[i] != a->gen) { *found = 0; return i; }
+        if (a->hk[i] == wid) { *found = 1; return i; }
+    }
+}
+
 /* ------------------------------------------------------------------ plan */
 void mplan_free(mplan_t *pl) {
-    for (int t = 0; t < MGPU_MAX_TERMS; t++) free(pl->term_post[t]);
-    free(pl->wids); free(pl->fops);
+    m_arena_free(pl->arena);
     memset(pl, 0, sizeof(*pl));
 }
 
-static void fop_push(mplan_t *pl, int op, int a, uint64_t lo, uint64_t hi) {
-    if (pl->p.num_fops == pl->fops_cap) {
-        pl->fops_cap = pl->fops_cap ? pl->fops_cap * 2 : 16;
-        pl->fops = realloc(pl->fops, sizeof(mgpu_fop_t) * (size_t)pl->fops_cap);
-    }
-    mgpu_fop_t *f = &pl->fops[pl->p.num_fops++];
+typedef struct { mgpu_fop_t *v; int n, cap; } fops_t;
+static void fop_push(fops_t *fo, int op, int a, uint64_t lo, uint64_t hi) {
+    if (fo->n == fo->cap) return;                            /* cannot happen: cap is the tree's upper bound */
+    mgpu_fop_t *f = &fo->v[fo->n++];
     f->op = op; f->a = a; f->lo = lo; f->hi = hi;
 }
-
+static int filter_nodes(const m_filter_t *f) {
+    int n = 1;
+    for (int i = 0; i < f->num_children; i++) n += filter_nodes(f->children[i]);
+    return n;
+}
 static int check_op(int f, double a, double b) {            /* check_double_oper, filter_apply.c:127-144 */
     switch (f) {
         case MF_LT: return a < b;
@@ -118,7 +201,7 @@ static uint64_t lb_desc(const double *val, uint64_t n, double x) {
 
 /* Lowers one filter node (post order, filter_apply.c:207-213).  Returns 1 when the node
  * leaves a bitmap on the stack, 0 when the reference would leave fr_bmap NULL. */
-static int lower_filter(const mmirror_t *m, const m_filter_t *f, mplan_t *pl) {
+static int lower_filter(const mmirror_t *m, const m_filter_t *f, fops_t *pl) {
     const mshard_t *s = m->s;
     switch (f->type) {
         case MF_EQ: case MF_NE: {
@@ -221,109 +304,90 @@ static int lower_filter(const mmirror_t *m, const m_filter_t *f, mplan_t *pl) {
     }
 }
 
-/* pre (may be NULL): term results that the device already produced; pre_have[t] says which */
-static int mplan_build_with(const mmirror_t *m, const m_query_t *q, int capture, mplan_t *pl, m_termresult_t *pre, const uint8_t *pre_have) {
-    if (q->num_terms > MGPU_MAX_TERMS || q->num_words > MGPU_MAX_WORDS) { memset(pl, 0, sizeof(*pl)); return MGPU_E_LIMIT; }
-    const mshard_t *s = m->s;
-    /* lookup_terms (squery.c:144-167): the trie walk stays on the host unless the device did it */
-    m_termresult_t tr[M_MAX_QTERMS];
-    uint32_t exact_wid[M_MAX_QWORDS];
-    for (int t = 0; t < q->num_terms; t++) {
-        if (pre && pre_have[t]) { tr[t] = pre[t]; memset(&pre[t], 0, sizeof(pre[t])); }      /* ownership moves here */
-        else mdict_lookup_term(s->dict, &q->terms[t], &tr[t]);
-    }
-    for (int i = 0; i < q->num_words; i++) exact_wid[i] = mdict_lookup_exact(s->dict, &q->words[i]);
-    int rc = mplan_from_terms(m, q, tr, exact_wid, capture, pl);
-    for (int t = 0; t < q->num_terms; t++) m_termresult_free(&tr[t]);
-    return rc;
-}
 
-int mplan_build(const mmirror_t *m, const m_query_t *q, int capture, mplan_t *pl) { return mplan_build_with(m, q, capture, pl, NULL, NULL); }
-
-/* Everything of the plan after the trie walk.  tr[t] = dtrie_lookup_term's result for term t (its wordids map
- * is extended here with the words under a twid, as set_wids_under_twid does, squery.c:62-70); exact_wid[i] =
- * dtrie_lookup_exact's result for query word i (0 = none).  q->terms / q->words themselves are not read, so a
- * caller whose dictionary is not an mdict (the reference's dtrie: shim/squery_gpu.c) can use it as is. */
-int mplan_from_terms(const mmirror_t *m, const m_query_t *q, m_termresult_t *tr, const uint32_t *exact_in,
-                     int capture, mplan_t *pl) {
-    memset(pl, 0, sizeof(*pl));
+/* One (query, shard) plan from flat term results: everything of lookup_terms after the dictionary (process_termresult,
+ * squery.c:72-118; exact wids, squery.c:159-166), the filter leaves, the config.  Term t's dictionary result is
+ * {twid[t], (t_wid[t][k], t_dist[t][k]) for k < t_n[t]} (dtrie.h:94-97); exact_in[i] = dtrie_lookup_exact of word i.
+ * Everything the plan points to is taken from `A`; *wids_out = the wid table (all_wordids + exact-only entries). */
+static int plan_build_flat(const mmirror_t *m, const m_query_t *q, const uint32_t *twid, const uint32_t *const *t_wid,
+                           const uint8_t *const *t_dist, const uint32_t *t_n, const uint32_t *exact_in, int capture,
+                           m_arena_t *A, mgpu_plan_t *p, mgpu_wid_entry_t **wids_out) {
+    memset(p, 0, sizeof(*p));
+    if (wids_out) *wids_out = NULL;
     const mshard_t *s = m->s;
-    mgpu_plan_t *p = &pl->p;
     p->num_terms = q->num_terms; p->num_words = q->num_words;
     if (q->num_terms > MGPU_MAX_TERMS || q->num_words > MGPU_MAX_WORDS) return MGPU_E_LIMIT;
+    const int nt = q->num_terms, nwords = q->num_words;
 
-    m_u32map_t all; m_u32map_init(&all);
-    /* process_termresult (squery.c:72-118) */
-    for (int t = 0; t < q->num_terms; t++) {
+    /* upper bound of the distinct wids this plan can name */
+    uint32_t ub = (uint32_t)nwords + 1;
+    for (int t = 0; t < nt; t++) {
+        if (twid[t]) { const uint32_t *w; ub += (uint32_t)mshard_twid_wids(s, twid[t], &w); }
+        else ub += t_n[t];
+    }
+    if (wt_begin(A, ub)) return MGPU_E_LIMIT;
+    mgpu_wid_entry_t *W = arena_alloc(A, sizeof(mgpu_wid_entry_t) * ub);
+    if (!W) return MGPU_E_LIMIT;
+    uint32_t nw = 0;
+    /* all_wordids: the LAST term that names a word sets its distance (kh_set, squery.c:56-60), the FIRST is its matching
+     * term (get_matching_term walks the terms in order, docrank.c:114-123) */
+#define ALL_SET(wid_, dist_, t_) do { int fnd_; const uint32_t sl_ = wt_find(A, (wid_), &fnd_); \
+        if (fnd_) W[A->hv[sl_]].dist = (uint8_t)(dist_); \
+        else { A->hg[sl_] = A->gen; A->hk[sl_] = (wid_); A->hv[sl_] = nw; \
+               W[nw].wid = (wid_); W[nw].dist = (uint8_t)(dist_); W[nw].mterm = (uint8_t)(t_); W[nw].exact_mask = 0; nw++; } } while (0)
+    for (int t = 0; t < nt; t++) {
         const uint32_t *docs;
-        if (tr[t].twid == 0 && tr[t].wordids.n == 0) { p->term_npost[t] = 0; continue; }
-        if (tr[t].twid) {
-            uint64_t n = mshard_twid_posting(s, tr[t].twid, &docs);
-            pl->term_post[t] = malloc(sizeof(uint32_t));
-            if (n) {
-                pl->term_post[t][0] = m->W + tr[t].twid;
+        if (twid[t] == 0 && t_n[t] == 0) continue;
+        if (twid[t]) {
+            uint32_t *tp = arena_alloc(A, sizeof(uint32_t));
+            if (!tp) return MGPU_E_LIMIT;
+            p->term_post[t] = tp;
+            if (mshard_twid_posting(s, twid[t], &docs)) {
+                tp[0] = m->W + twid[t];
                 p->term_npost[t] = 1; p->term_nzero[t] = 1;          /* a twid matches with zero typos (squery.c:87-88) */
                 const uint32_t *wids;
-                uint64_t nw = mshard_twid_wids(s, tr[t].twid, &wids);
-                for (uint64_t i = 0; i < nw; i++) { m_u32map_set(&tr[t].wordids, wids[i], 0); m_u32map_set(&all, wids[i], 0); }
+                const uint64_t n = mshard_twid_wids(s, twid[t], &wids);          /* set_wids_under_twid, squery.c:62-70 */
+                for (uint64_t i = 0; i < n; i++) ALL_SET(wids[i], 0, t);
             }
             continue;
         }
-        pl->term_post[t] = malloc(sizeof(uint32_t) * (tr[t].wordids.n ? tr[t].wordids.n : 1));
+        uint32_t *tp = arena_alloc(A, sizeof(uint32_t) * t_n[t]);
+        if (!tp) return MGPU_E_LIMIT;
+        p->term_post[t] = tp;
         uint32_t np = 0, nz = 0;
-        for (uint32_t k = 0; k < tr[t].wordids.cap; k++) {
-            uint32_t wid = tr[t].wordids.keys[k];
-            if (!wid) continue;
-            if (!mshard_wid_posting(s, wid, &docs)) continue;
-            m_u32map_set(&all, wid, tr[t].wordids.vals[k]);
-            pl->term_post[t][np++] = wid;
-            if (tr[t].wordids.vals[k] == 0) {                        /* zero typos: kept in front (tzero_typo_bmap) */
-                uint32_t x = pl->term_post[t][nz]; pl->term_post[t][nz] = wid; pl->term_post[t][np - 1] = x; nz++;
-            }
+        const uint32_t *tw = t_wid[t]; const uint8_t *td = t_dist[t];
+        for (uint32_t k = 0; k < t_n[t]; k++) {
+            const uint32_t wid = tw[k];
+            if (!wid || !mshard_wid_posting(s, wid, &docs)) continue;
+            ALL_SET(wid, td[k], t);
+            tp[np++] = wid;
+            if (td[k] == 0) { const uint32_t x = tp[nz]; tp[nz] = wid; tp[np - 1] = x; nz++; }   /* zero typos: kept in front (tzero_typo_bmap) */
         }
         p->term_npost[t] = np; p->term_nzero[t] = nz;
     }
-    for (int t = 0; t < q->num_terms; t++) p->term_post[t] = pl->term_post[t];
-
-    /* exact wids (squery.c:159-166) */
-    uint32_t exact_wid[M_MAX_QWORDS];
-    for (int i = 0; i < q->num_words; i++) {
+#undef ALL_SET
+    /* exact wids (squery.c:159-166): bits on the entries they share with all_wordids, entries of their own otherwise */
+    for (int i = 0; i < nwords; i++) {
         const uint32_t *docs;
-        uint32_t wid = exact_in[i];
-        exact_wid[i] = 0;
-        if (wid && mshard_wid_posting(s, wid, &docs)) { exact_wid[i] = wid; p->exact_present |= (uint16_t)(1u << i); }
+        const uint32_t wid = exact_in[i];
+        if (!wid || !mshard_wid_posting(s, wid, &docs)) continue;
+        p->exact_present |= (uint16_t)(1u << i);
+        int fnd; const uint32_t sl = wt_find(A, wid, &fnd);
+        if (fnd) { W[A->hv[sl]].exact_mask |= (uint16_t)(1u << i); continue; }
+        A->hg[sl] = A->gen; A->hk[sl] = wid; A->hv[sl] = nw;
+        W[nw].wid = wid; W[nw].dist = 0xFF; W[nw].mterm = 0xFF; W[nw].exact_mask = (uint16_t)(1u << i); nw++;
     }
-    /* wid table: all_wordids distance, first matching term, exact bits */
-    {
-        uint32_t cap = all.n + (uint32_t)q->num_words + 1;
-        pl->wids = malloc(sizeof(mgpu_wid_entry_t) * cap);
-        uint32_t nw = 0;
-        for (uint32_t k = 0; k < all.cap; k++) {
-            uint32_t wid = all.keys[k];
-            if (!wid) continue;
-            mgpu_wid_entry_t *e = &pl->wids[nw++];
-            e->wid = wid; e->dist = (uint8_t)all.vals[k]; e->mterm = 0xFF; e->exact_mask = 0;
-            for (int t = 0; t < q->num_terms; t++)
-                if (m_u32map_get(&tr[t].wordids, wid, 0xFF) != 0xFF) { e->mterm = (uint8_t)t; break; }
-            for (int i = 0; i < q->num_words; i++) if (exact_wid[i] == wid) e->exact_mask |= (uint16_t)(1u << i);
-        }
-        for (int i = 0; i < q->num_words; i++) {
-            if (!exact_wid[i] || m_u32map_get(&all, exact_wid[i], -1) >= 0) continue;
-            int dup = 0;
-            for (uint32_t k = all.n; k < nw; k++) if (pl->wids[k].wid == exact_wid[i]) { pl->wids[k].exact_mask |= (uint16_t)(1u << i); dup = 1; }
-            if (dup) continue;
-            mgpu_wid_entry_t *e = &pl->wids[nw++];
-            e->wid = exact_wid[i]; e->dist = 0xFF; e->mterm = 0xFF; e->exact_mask = (uint16_t)(1u << i);
-        }
-        p->num_wids = nw; p->wids = pl->wids;
-    }
-    m_u32map_free(&all);
+    p->num_wids = nw; p->wids = W;
+    if (wids_out) *wids_out = W;
 
     /* filter */
     if (q->filter) {
+        fops_t fo; fo.n = 0; fo.cap = 4 * filter_nodes(q->filter) + 4;
+        fo.v = arena_alloc(A, sizeof(mgpu_fop_t) * (size_t)fo.cap);
+        if (!fo.v) return MGPU_E_LIMIT;
         p->has_filter = 1;
-        p->filter_null = lower_filter(m, q->filter, pl) ? 0 : 1;
-        p->fops = pl->fops;
+        p->filter_null = lower_filter(m, q->filter, &fo) ? 0 : 1;
+        p->fops = fo.v; p->num_fops = fo.n;
     }
     /* config */
     p->hits_per_page = q->cfg.hits_per_page; p->page_num = q->page_num;
@@ -339,144 +403,286 @@ int mplan_from_terms(const mmirror_t *m, const m_query_t *q, m_termresult_t *tr,
     return 0;
 }
 
+/* Everything of the plan after the trie walk, from the reference's own result type: tr[t] = dtrie_lookup_term's result
+ * for term t (a khash of wid -> distance there, an m_u32map here); exact_in[i] = dtrie_lookup_exact's result for query
+ * word i (0 = none).  q->terms / q->words themselves are not read, so a caller whose dictionary is not an mdict (the
+ * reference's dtrie: shim/squery_gpu.c) can use it as is.  tr is not modified. */
+int mplan_from_terms(const mmirror_t *m, const m_query_t *q, m_termresult_t *tr, const uint32_t *exact_in,
+                     int capture, mplan_t *pl) {
+    memset(pl, 0, sizeof(*pl));
+    if (q->num_terms > MGPU_MAX_TERMS || q->num_words > MGPU_MAX_WORDS) return MGPU_E_LIMIT;
+    pl->arena = m_arena_new();
+    if (!pl->arena) return MGPU_E_LIMIT;
+    uint32_t twid[M_MAX_QTERMS], t_n[M_MAX_QTERMS];
+    const uint32_t *t_wid[M_MAX_QTERMS]; const uint8_t *t_dist[M_MAX_QTERMS];
+    for (int t = 0; t < q->num_terms; t++) {
+        const m_u32map_t *mp = &tr[t].wordids;
+        twid[t] = tr[t].twid; t_n[t] = 0; t_wid[t] = NULL; t_dist[t] = NULL;
+        if (twid[t] || !mp->n) continue;
+        uint32_t *w = arena_alloc(pl->arena, sizeof(uint32_t) * mp->n);
+        uint8_t *d = arena_alloc(pl->arena, mp->n);
+        if (!w || !d) return MGPU_E_LIMIT;
+        uint32_t n = 0;
+        for (uint32_t k = 0; k < mp->cap; k++) if (mp->keys[k]) { w[n] = mp->keys[k]; d[n] = (uint8_t)mp->vals[k]; n++; }
+        t_n[t] = n; t_wid[t] = w; t_dist[t] = d;
+    }
+    return plan_build_flat(m, q, twid, t_wid, t_dist, t_n, exact_in, capture, pl->arena, &pl->p, &pl->wids);
+}
+
+/* lookup_terms (squery.c:144-167) with the host dictionary, then the plan */
+int mplan_build(const mmirror_t *m, const m_query_t *q, int capture, mplan_t *pl) {
+    if (q->num_terms > MGPU_MAX_TERMS || q->num_words > MGPU_MAX_WORDS) { memset(pl, 0, sizeof(*pl)); return MGPU_E_LIMIT; }
+    const mshard_t *s = m->s;
+    m_termresult_t tr[M_MAX_QTERMS];
+    uint32_t exact_wid[M_MAX_QWORDS];
+    for (int t = 0; t < q->num_terms; t++) mdict_lookup_term(s->dict, &q->terms[t], &tr[t]);
+    for (int i = 0; i < q->num_words; i++) exact_wid[i] = mdict_lookup_exact(s->dict, &q->words[i]);
+    int rc = mplan_from_terms(m, q, tr, exact_wid, capture, pl);
+    for (int t = 0; t < q->num_terms; t++) m_termresult_free(&tr[t]);
+    return rc;
+}
+
 /* ------------------------------------------------------------------ execution */
 int msq_plan_threads = 1;
 void msq_set_plan_threads(int n) { msq_plan_threads = n; }
+mgpu_shard_t *mmirror_gpu(mmirror_t *m) { return m ? m->g : NULL; }
 
-struct plan_job {
-    mmirror_t *const *mirrors; int num_shards; const m_query_t *const *queries; int capture;
-    mplan_t *plans; mgpu_plan_t *gp; mgpu_shard_t **gs; int lo, hi, rc;
-    m_termresult_t *pre; uint8_t *pre_have;        /* per (query, shard) M_MAX_QTERMS entries each, or NULL */
+/* ---- resolved queries: the dictionary half of lookup_terms for nq queries x num_shards shards, kept flat.
+ * Pair i = (query i / num_shards, shard i % num_shards); its term t is entry i * M_MAX_QTERMS + t. */
+struct msq_resolved {
+    int n, nq, num_shards;
+    mmirror_t *const *mirrors; const m_query_t **queries;
+    uint32_t *twid;            /* [n * M_MAX_QTERMS] */
+    uint32_t *t_off;           /* [n * M_MAX_QTERMS + 1] into wid / dist */
+    uint32_t *wid; uint8_t *dist;
+    uint32_t *exact;           /* [n * M_MAX_QWORDS] */
+    size_t nwd;
 };
-static void *plan_worker(void *arg) {
-    struct plan_job *j = arg;
+
+void msq_resolved_free(msq_resolved_t *r) {
+    if (!r) return;
+    free(r->queries); free(r->twid); free(r->t_off); free(r->wid); free(r->dist); free(r->exact); free(r);
+}
+int msq_resolved_count(const msq_resolved_t *r) { return r ? r->nq : 0; }
+
+struct resolve_job { mmirror_t *const *mirrors; int num_shards; const m_query_t *const *queries; m_termresult_t *tr; const uint8_t *have;
+                     uint32_t *exact; int lo, hi; };
+static void *resolve_worker(void *arg) {
+    struct resolve_job *j = arg;
     for (int i = j->lo; i < j->hi; i++) {
-        int qi = i / j->num_shards, sidx = i % j->num_shards;
-        int rc = mplan_build_with(j->mirrors[sidx], j->queries[qi], j->capture, &j->plans[i],
-                                  j->pre ? j->pre + (size_t)i * M_MAX_QTERMS : NULL, j->pre ? j->pre_have + (size_t)i * M_MAX_QTERMS : NULL);
-        if (rc) j->rc = rc;
-        j->gp[i] = j->plans[i].p;
-        j->gs[i] = j->mirrors[sidx]->g;
+        const m_query_t *q = j->queries[i / j->num_shards];
+        const mshard_t *s = j->mirrors[i % j->num_shards]->s;
+        if (q->num_terms > M_MAX_QTERMS || q->num_words > M_MAX_QWORDS) continue;
+        for (int t = 0; t < q->num_terms; t++)
+            if (!j->have[(size_t)i * M_MAX_QTERMS + t]) mdict_lookup_term(s->dict, &q->terms[t], &j->tr[(size_t)i * M_MAX_QTERMS + t]);
+        for (int w = 0; w < q->num_words; w++) j->exact[(size_t)i * M_MAX_QWORDS + w] = mdict_lookup_exact(s->dict, &q->words[w]);
     }
     return NULL;
 }
 
-mgpu_shard_t *mmirror_gpu(mmirror_t *m) { return m ? m->g : NULL; }
-
-struct msq_prepared {
-    int n, nq, num_shards;
-    mmirror_t *const *mirrors; const m_query_t **queries;
-    mplan_t *plans; mgpu_plan_t *gp; mgpu_shard_t **gs;
-};
-
-/* lookup_terms (squery.c:144-167) + filter leaf resolution for every (query, shard) pair */
-static int prepare_common(mmirror_t *const *mirrors, int num_shards, const m_query_t *const *queries,
-                          int nq, int capture, m_termresult_t *pre, uint8_t *pre_have, msq_prepared_t **out) {
-    int n = nq * num_shards;
-    msq_prepared_t *pp = calloc(1, sizeof(*pp));
-    pp->n = n; pp->nq = nq; pp->num_shards = num_shards; pp->mirrors = mirrors;
-    pp->queries = calloc((size_t)(nq ? nq : 1), sizeof(*pp->queries));
-    memcpy(pp->queries, queries, (size_t)nq * sizeof(*pp->queries));
-    pp->plans = calloc((size_t)(n ? n : 1), sizeof(mplan_t));
-    pp->gp = calloc((size_t)(n ? n : 1), sizeof(mgpu_plan_t));
-    pp->gs = calloc((size_t)(n ? n : 1), sizeof(mgpu_shard_t *));
-    int rc = 0;
-    int nthreads = msq_plan_threads;
-    if (nthreads > n) nthreads = n;
-    if (nthreads < 1) nthreads = 1;
-    if (nthreads > 64) nthreads = 64;
-    struct plan_job jobs[64];
-    pthread_t th[64];
-    for (int t = 0; t < nthreads; t++) {
-        jobs[t].mirrors = mirrors; jobs[t].num_shards = num_shards; jobs[t].queries = queries;
-        jobs[t].capture = capture; jobs[t].plans = pp->plans; jobs[t].gp = pp->gp; jobs[t].gs = pp->gs;
-        jobs[t].lo = (int)((long)n * t / nthreads); jobs[t].hi = (int)((long)n * (t + 1) / nthreads); jobs[t].rc = 0;
-        jobs[t].pre = pre; jobs[t].pre_have = pre_have;
-    }
-    if (nthreads == 1) plan_worker(&jobs[0]);
-    else {
-        for (int t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, plan_worker, &jobs[t]);
-        for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
-    }
-    for (int t = 0; t < nthreads; t++) if (jobs[t].rc) rc = jobs[t].rc;
-    if (rc) { msq_prepared_free(pp); pp = NULL; }
-    *out = pp;
-    return rc;
-}
-
-int msq_prepare_batch(mmirror_t *const *mirrors, int num_shards, const m_query_t *const *queries,
-                      int nq, int capture, msq_prepared_t **out) {
-    return prepare_common(mirrors, num_shards, queries, nq, capture, NULL, NULL, out);
-}
-
-int msq_prepare_batch_dev(mgpu_ctx_t *ctx, mmirror_t *const *mirrors, int num_shards, const m_query_t *const *queries,
-                          int nq, int capture, msq_prepared_t **out) {
+/* dtrie_lookup_term for every term and dtrie_lookup_exact for every word of every (query, shard) pair.  ctx != NULL: the
+ * typo walks (dtrie.c:763-791) run on the device, ONE mgpu_lookup_terms call for the whole set (row f-1; ctx must be idle
+ * and on the mirrors' device); the exact descents stay on the host (msq_plan_threads threads). */
+int msq_resolve_batch(mgpu_ctx_t *ctx, mmirror_t *const *mirrors, int num_shards, const m_query_t *const *queries, int nq,
+                      msq_resolved_t **out) {
     *out = NULL;
+    if (nq < 0 || num_shards < 1) return MGPU_E_ARG;
     const int n = nq * num_shards;
-    if (n <= 0) return prepare_common(mirrors, num_shards, queries, nq, capture, NULL, NULL, out);
-    m_termresult_t *pre = calloc((size_t)n * M_MAX_QTERMS, sizeof(*pre));
-    uint8_t *have = calloc((size_t)n * M_MAX_QTERMS, 1);
-    /* every term that dtrie_lookup_term would walk the trie for (mode 2) becomes one device lookup */
-    size_t nl = 0;
-    for (int i = 0; i < n; i++) {
-        const m_query_t *q = queries[i / num_shards];
-        if (!mirrors[i % num_shards]->gd || q->num_terms > M_MAX_QTERMS) continue;
-        for (int t = 0; t < q->num_terms; t++)
-            if (mdict_lookup_mode(&q->terms[t]) == 2 && q->terms[t].word.length >= 1 && q->terms[t].word.length <= MGPU_MAX_TERM_LEN) nl++;
-    }
-    mgpu_term_lookup_t *lk = malloc(sizeof(*lk) * (nl ? nl : 1));
-    uint32_t *slot = malloc(sizeof(uint32_t) * (nl ? nl : 1));          /* lookup -> index into pre[] */
-    nl = 0;
-    for (int i = 0; i < n; i++) {
-        const m_query_t *q = queries[i / num_shards];
-        if (!mirrors[i % num_shards]->gd || q->num_terms > M_MAX_QTERMS) continue;
-        for (int t = 0; t < q->num_terms; t++) {
-            const m_term_t *tm = &q->terms[t];
-            if (mdict_lookup_mode(tm) != 2 || tm->word.length < 1 || tm->word.length > MGPU_MAX_TERM_LEN) continue;
-            lk[nl].dict = mirrors[i % num_shards]->gd; lk[nl].chars = tm->word.chars; lk[nl].len = tm->word.length; lk[nl].prefix = tm->prefix;
-            slot[nl] = (uint32_t)((size_t)i * M_MAX_QTERMS + (size_t)t);
-            have[slot[nl]] = 1;                                      /* an empty result is a result too */
-            nl++;
-        }
-    }
+    for (int i = 0; i < nq; i++) if (queries[i]->num_terms > M_MAX_QTERMS || queries[i]->num_words > M_MAX_QWORDS) return MGPU_E_LIMIT;
+    msq_resolved_t *r = calloc(1, sizeof(*r));
+    m_termresult_t *tr = calloc((size_t)(n ? n : 1) * M_MAX_QTERMS, sizeof(*tr));
+    uint8_t *have = calloc((size_t)(n ? n : 1) * M_MAX_QTERMS, 1);
+    if (!r || !tr || !have) { free(r); free(tr); free(have); return MGPU_E_LIMIT; }
+    r->n = n; r->nq = nq; r->num_shards = num_shards; r->mirrors = mirrors;
+    r->queries = calloc((size_t)(nq ? nq : 1), sizeof(*r->queries));
+    memcpy(r->queries, queries, (size_t)nq * sizeof(*r->queries));
+    r->twid = calloc((size_t)(n ? n : 1) * M_MAX_QTERMS, sizeof(uint32_t));
+    r->t_off = calloc((size_t)(n ? n : 1) * M_MAX_QTERMS + 1, sizeof(uint32_t));
+    r->exact = calloc((size_t)(n ? n : 1) * M_MAX_QWORDS, sizeof(uint32_t));
     int rc = 0;
     static int trace = -1;
     if (trace < 0) trace = getenv("MSQ_PREP_TRACE") != NULL;
     struct timespec ts0, ts1, ts2;
     clock_gettime(CLOCK_MONOTONIC, &ts0);
-    size_t nhits_total = 0;
-    /* at most 65535 lookups per call */
-    for (size_t lo = 0; lo < nl && !rc; lo += 65535) {
-        const int cnt = (int)(nl - lo < 65535 ? nl - lo : 65535);
-        mgpu_term_hit_t *hits = NULL; uint32_t nh = 0;
-        rc = mgpu_lookup_terms(ctx, lk + lo, cnt, &hits, &nh);
-        if (rc) break;
-        for (uint32_t h = 0; h < nh; h++) {
-            if (hits[h].lookup >= (uint32_t)cnt) { rc = MGPU_E_HIP; break; }
-            m_termresult_t *tr = &pre[slot[lo + hits[h].lookup]];
-            /* add_wordid_to_result (dtrie.c:633-640): least distance */
-            if ((int)hits[h].dist < m_u32map_get(&tr->wordids, hits[h].wid, 0xFF)) m_u32map_set(&tr->wordids, hits[h].wid, (int32_t)hits[h].dist);
+    size_t nl = 0, nhits_total = 0;
+    if (ctx && n) {
+        /* every term that dtrie_lookup_term would walk the trie for (mode 2) becomes one device lookup */
+        for (int i = 0; i < n; i++) {
+            const m_query_t *q = queries[i / num_shards];
+            if (!mirrors[i % num_shards]->gd) continue;
+            for (int t = 0; t < q->num_terms; t++)
+                if (mdict_lookup_mode(&q->terms[t]) == 2 && q->terms[t].word.length >= 1 && q->terms[t].word.length <= MGPU_MAX_TERM_LEN) nl++;
         }
-        nhits_total += nh;
-        mgpu_term_hits_free(hits);
+        mgpu_term_lookup_t *lk = malloc(sizeof(*lk) * (nl ? nl : 1));
+        uint32_t *slot = malloc(sizeof(uint32_t) * (nl ? nl : 1));          /* lookup -> index into tr[] */
+        nl = 0;
+        for (int i = 0; i < n; i++) {
+            const m_query_t *q = queries[i / num_shards];
+            if (!mirrors[i % num_shards]->gd) continue;
+            for (int t = 0; t < q->num_terms; t++) {
+                const m_term_t *tm = &q->terms[t];
+                if (mdict_lookup_mode(tm) != 2 || tm->word.length < 1 || tm->word.length > MGPU_MAX_TERM_LEN) continue;
+                lk[nl].dict = mirrors[i % num_shards]->gd; lk[nl].chars = tm->word.chars; lk[nl].len = tm->word.length; lk[nl].prefix = tm->prefix;
+                slot[nl] = (uint32_t)((size_t)i * M_MAX_QTERMS + (size_t)t);
+                have[slot[nl]] = 1;                                      /* an empty result is a result too */
+                nl++;
+            }
+        }
+        /* at most 65535 lookups per call */
+        for (size_t lo = 0; lo < nl && !rc; lo += 65535) {
+            const int cnt = (int)(nl - lo < 65535 ? nl - lo : 65535);
+            mgpu_term_hit_t *hits = NULL; uint32_t nh = 0;
+            rc = mgpu_lookup_terms(ctx, lk + lo, cnt, &hits, &nh);
+            if (rc) break;
+            for (uint32_t h = 0; h < nh; h++) {
+                if (hits[h].lookup >= (uint32_t)cnt) { rc = MGPU_E_HIP; break; }
+                m_termresult_t *x = &tr[slot[lo + hits[h].lookup]];
+                /* add_wordid_to_result (dtrie.c:633-640): least distance */
+                if ((int)hits[h].dist < m_u32map_get(&x->wordids, hits[h].wid, 0xFF)) m_u32map_set(&x->wordids, hits[h].wid, (int32_t)hits[h].dist);
+            }
+            nhits_total += nh;
+            mgpu_term_hits_free(hits);
+        }
+        free(lk); free(slot);
     }
-    free(lk); free(slot);
     clock_gettime(CLOCK_MONOTONIC, &ts1);
-    if (!rc) rc = prepare_common(mirrors, num_shards, queries, nq, capture, pre, have, out);
+    if (!rc && n) {
+        int nthreads = msq_plan_threads;
+        if (nthreads > n) nthreads = n;
+        if (nthreads < 1) nthreads = 1;
+        if (nthreads > 64) nthreads = 64;
+        struct resolve_job jobs[64];
+        pthread_t th[64];
+        for (int t = 0; t < nthreads; t++) {
+            jobs[t] = (struct resolve_job){ mirrors, num_shards, queries, tr, have, r->exact,
+                                            (int)((long)n * t / nthreads), (int)((long)n * (t + 1) / nthreads) };
+        }
+        if (nthreads == 1) resolve_worker(&jobs[0]);
+        else {
+            for (int t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, resolve_worker, &jobs[t]);
+            for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+        }
+        /* flatten */
+        size_t tot = 0;
+        for (size_t k = 0; k < (size_t)n * M_MAX_QTERMS; k++) tot += tr[k].wordids.n;
+        if (tot >= 0xFFFFFFFFull) rc = MGPU_E_LIMIT;
+        else {
+            r->wid = malloc(sizeof(uint32_t) * (tot ? tot : 1)); r->dist = malloc(tot ? tot : 1);
+            size_t at = 0;
+            for (size_t k = 0; k < (size_t)n * M_MAX_QTERMS; k++) {
+                r->t_off[k] = (uint32_t)at;
+                r->twid[k] = tr[k].twid;
+                const m_u32map_t *mp = &tr[k].wordids;
+                for (uint32_t x = 0; x < mp->cap; x++) if (mp->keys[x]) { r->wid[at] = mp->keys[x]; r->dist[at] = (uint8_t)mp->vals[x]; at++; }
+            }
+            r->t_off[(size_t)n * M_MAX_QTERMS] = (uint32_t)at;
+            r->nwd = at;
+        }
+    }
     if (trace) {
         clock_gettime(CLOCK_MONOTONIC, &ts2);
-        fprintf(stderr, "[prepare_dev] %zu lookups, %zu hits: device scan + maps %.3f ms, plans %.3f ms\n", nl, nhits_total,
+        fprintf(stderr, "[resolve] %d pairs, %zu device lookups, %zu hits: device scan + maps %.3f ms, host descents + flatten %.3f ms\n", n, nl, nhits_total,
                 (ts1.tv_sec - ts0.tv_sec) * 1e3 + (ts1.tv_nsec - ts0.tv_nsec) * 1e-6, (ts2.tv_sec - ts1.tv_sec) * 1e3 + (ts2.tv_nsec - ts1.tv_nsec) * 1e-6);
     }
-    for (size_t i = 0; i < (size_t)n * M_MAX_QTERMS; i++) if (pre[i].wordids.cap) m_termresult_free(&pre[i]);
-    free(pre); free(have);
+    for (size_t k = 0; k < (size_t)(n ? n : 1) * M_MAX_QTERMS; k++) if (tr[k].wordids.cap) m_termresult_free(&tr[k]);
+    free(tr); free(have);
+    if (rc) { msq_resolved_free(r); return rc; }
+    *out = r;
+    return 0;
+}
+
+/* ---- prepared batches: the plans of a resolved set, all in one arena */
+struct msq_prepared {
+    int n, nq, num_shards;
+    mmirror_t *const *mirrors; const m_query_t **queries;      /* borrowed from the resolved set when `borrowed` */
+    mgpu_plan_t *gp; mgpu_shard_t **gs;
+    m_arena_t *arena;
+    int borrowed;
+};
+
+msq_prepared_t *msq_prepared_new(void) {
+    msq_prepared_t *pp = calloc(1, sizeof(*pp));
+    if (pp && !(pp->arena = m_arena_new())) { free(pp); pp = NULL; }
+    return pp;
+}
+
+/* process_termresult + exact wids + filter leaves + config for every pair of `r`, written into pp (whose previous
+ * contents are dropped; its arena is reused).  Single-threaded: the serving loop runs one of these per host thread. */
+int msq_plan_resolved(const msq_resolved_t *r, int capture, msq_prepared_t *pp) {
+    if (!r || !pp) return MGPU_E_ARG;
+    m_arena_reset(pp->arena);
+    if (!pp->borrowed) free(pp->queries);
+    pp->n = r->n; pp->nq = r->nq; pp->num_shards = r->num_shards; pp->mirrors = r->mirrors;
+    pp->queries = r->queries; pp->borrowed = 1;
+    const int n = r->n;
+    pp->gp = arena_alloc(pp->arena, sizeof(mgpu_plan_t) * (size_t)(n ? n : 1));
+    pp->gs = arena_alloc(pp->arena, sizeof(mgpu_shard_t *) * (size_t)(n ? n : 1));
+    if (!pp->gp || !pp->gs) return MGPU_E_LIMIT;
+    int rc = 0;
+    for (int i = 0; i < n; i++) {
+        const m_query_t *q = r->queries[i / r->num_shards];
+        const mmirror_t *m = r->mirrors[i % r->num_shards];
+        const uint32_t *t_wid[M_MAX_QTERMS]; const uint8_t *t_dist[M_MAX_QTERMS]; uint32_t t_n[M_MAX_QTERMS];
+        const size_t b = (size_t)i * M_MAX_QTERMS;
+        for (int t = 0; t < q->num_terms; t++) {
+            t_wid[t] = r->wid + r->t_off[b + t]; t_dist[t] = r->dist + r->t_off[b + t];
+            t_n[t] = r->t_off[b + t + 1] - r->t_off[b + t];
+        }
+        const int r1 = plan_build_flat(m, q, r->twid + b, t_wid, t_dist, t_n, r->exact + (size_t)i * M_MAX_QWORDS, capture,
+                                       pp->arena, &pp->gp[i], NULL);
+        if (r1) rc = r1;
+        pp->gs[i] = m->g;
+    }
     return rc;
+}
+
+/* test / inspection access: plan i of a prepared batch; term t of pair i of a resolved set */
+const mgpu_plan_t *msq_prepared_plan(const msq_prepared_t *pp, int i) { return (pp && i >= 0 && i < pp->n) ? &pp->gp[i] : NULL; }
+uint32_t msq_resolved_term(const msq_resolved_t *r, int i, int t, uint32_t *twid, const uint32_t **wid, const uint8_t **dist) {
+    if (!r || i < 0 || i >= r->n || t < 0 || t >= M_MAX_QTERMS) return 0;
+    const size_t k = (size_t)i * M_MAX_QTERMS + (size_t)t;
+    if (twid) *twid = r->twid[k];
+    if (wid) *wid = r->wid + r->t_off[k];
+    if (dist) *dist = r->dist + r->t_off[k];
+    return r->t_off[k + 1] - r->t_off[k];
+}
+uint32_t msq_resolved_exact(const msq_resolved_t *r, int i, int w) {
+    return (r && i >= 0 && i < r->n && w >= 0 && w < M_MAX_QWORDS) ? r->exact[(size_t)i * M_MAX_QWORDS + w] : 0;
+}
+
+static int prepare_common(mgpu_ctx_t *ctx, mmirror_t *const *mirrors, int num_shards, const m_query_t *const *queries,
+                          int nq, int capture, msq_prepared_t **out) {
+    *out = NULL;
+    msq_resolved_t *r = NULL;
+    int rc = msq_resolve_batch(ctx, mirrors, num_shards, queries, nq, &r);
+    if (rc) return rc;
+    msq_prepared_t *pp = msq_prepared_new();
+    if (!pp) { msq_resolved_free(r); return MGPU_E_LIMIT; }
+    rc = msq_plan_resolved(r, capture, pp);
+    /* the prepared batch outlives the resolved set: it keeps its own copy of the query pointers */
+    pp->queries = r->queries; r->queries = NULL; pp->borrowed = 0;
+    msq_resolved_free(r);
+    if (rc) { msq_prepared_free(pp); return rc; }
+    *out = pp;
+    return 0;
+}
+
+/* lookup_terms (squery.c:144-167) + filter leaf resolution for every (query, shard) pair */
+int msq_prepare_batch(mmirror_t *const *mirrors, int num_shards, const m_query_t *const *queries,
+                      int nq, int capture, msq_prepared_t **out) {
+    return prepare_common(NULL, mirrors, num_shards, queries, nq, capture, out);
+}
+
+int msq_prepare_batch_dev(mgpu_ctx_t *ctx, mmirror_t *const *mirrors, int num_shards, const m_query_t *const *queries,
+                          int nq, int capture, msq_prepared_t **out) {
+    return prepare_common(ctx, mirrors, num_shards, queries, nq, capture, out);
 }
 
 void msq_prepared_free(msq_prepared_t *pp) {
     if (!pp) return;
-    for (int i = 0; i < pp->n; i++) mplan_free(&pp->plans[i]);
-    free(pp->plans); free(pp->gp); free(pp->gs); free(pp->queries); free(pp);
+    m_arena_free(pp->arena);
+    if (!pp->borrowed) free(pp->queries);
+    free(pp);
 }
 
 int msq_execute_batch(mgpu_ctx_t *ctx, mmirror_t *const *mirrors, int num_shards,
@@ -598,8 +804,11 @@ struct msq_pipeline {
     /* thread t owns contexts 2t and 2t + 1 (the last thread only one when nctx is odd): while it decodes and
      * merges one batch, its next one is already queued on the GPU */
     mgpu_ctx_t *ctx[128];
-    /* the current run */
+    /* the current run: prepared batches (preps), or resolved sets whose plans every step builds first (res) */
     const msq_prepared_t *const *preps; int nprep, first, count, every;
+    const msq_resolved_t *const *res;
+    msq_prepared_t *slot_pp[128];         /* per context: the plans of the batch it has in flight (resolved runs) */
+    double plan_ms[64];                   /* per thread: wall time spent building plans in the last run */
     long hits[64]; int rc[64];
     char err[256];
 };
@@ -633,16 +842,29 @@ static int pipe_collect(msq_pipeline_t *p, int t, mgpu_ctx_t *ctx, const msq_pre
     return rc;
 }
 
+/* the batch of step i on context slot k of thread t: a prepared one, or plans built here and now from a resolved set
+ * (lookup_terms after the dictionary: process_termresult, squery.c:72-118) */
+static const msq_prepared_t *pipe_batch(msq_pipeline_t *p, int t, int ci, int i, int *rc) {
+    *rc = 0;
+    if (!p->res) return p->preps[(p->first + i) % p->nprep];
+    const double t0 = pipe_now();
+    if (!p->slot_pp[ci] && !(p->slot_pp[ci] = msq_prepared_new())) { *rc = MGPU_E_LIMIT; return NULL; }
+    *rc = msq_plan_resolved(p->res[(p->first + i) % p->nprep], 0, p->slot_pp[ci]);
+    p->plan_ms[t] += pipe_now() - t0;
+    return *rc ? NULL : p->slot_pp[ci];
+}
+
 static void pipe_steps(msq_pipeline_t *p, int t) {
-    p->hits[t] = 0; p->rc[t] = 0;
+    p->hits[t] = 0; p->rc[t] = 0; p->plan_ms[t] = 0;
     mgpu_ctx_t *cx[2] = { p->ctx[2 * t], (2 * t + 1 < p->nctx) ? p->ctx[2 * t + 1] : NULL };
     const int ncx = cx[1] ? 2 : 1;
     if (p->every) {
         /* warm-up run: every context of this thread takes every batch once */
         for (int k = 0; k < ncx; k++)
             for (int i = 0; i < p->count; i++) {
-                const msq_prepared_t *pp = p->preps[(p->first + i) % p->nprep];
-                int rc = msq_submit_prepared(cx[k], pp);
+                int rc;
+                const msq_prepared_t *pp = pipe_batch(p, t, 2 * t + k, i, &rc);
+                if (!rc) rc = msq_submit_prepared(cx[k], pp);
                 if (rc) { pipe_fail(p, t, rc); return; }
                 if (pipe_collect(p, t, cx[k], pp, NULL)) return;
             }
@@ -654,9 +876,10 @@ static void pipe_steps(msq_pipeline_t *p, int t) {
     int slot = 0;
     for (int i = t; i < p->count || inflight[0] || inflight[1]; i += p->nthreads) {
         if (i < p->count) {
-            const msq_prepared_t *pp = p->preps[(p->first + i) % p->nprep];
             tr[slot].step = i; tr[slot].t = t; tr[slot].sub0 = pipe_now() - p->t_run0;
-            int rc = msq_submit_prepared(cx[slot], pp);
+            int rc;
+            const msq_prepared_t *pp = pipe_batch(p, t, 2 * t + slot, i, &rc);
+            if (!rc) rc = msq_submit_prepared(cx[slot], pp);
             tr[slot].sub1 = pipe_now() - p->t_run0;
             if (rc) { pipe_fail(p, t, rc); break; }
             inflight[slot] = pp;
@@ -714,11 +937,11 @@ int msq_pipeline_create(mgpu_ctx_t *const *ctxs, int nctx, msq_pipeline_t **out)
     return 0;
 }
 
-static int pipe_dispatch(msq_pipeline_t *p, const msq_prepared_t *const *preps, int nprep, int first, int count,
-                         int every, long *hits_out) {
-    if (!p || !preps || nprep < 1 || count < 0) return MGPU_E_ARG;
+static int pipe_dispatch(msq_pipeline_t *p, const msq_prepared_t *const *preps, const msq_resolved_t *const *res, int nprep,
+                         int first, int count, int every, long *hits_out) {
+    if (!p || (!preps && !res) || nprep < 1 || count < 0) return MGPU_E_ARG;
     pthread_mutex_lock(&p->mu);
-    p->preps = preps; p->nprep = nprep; p->first = first; p->count = count; p->every = every;
+    p->preps = preps; p->res = res; p->nprep = nprep; p->first = first; p->count = count; p->every = every;
     p->err[0] = 0;
     p->ntrace = 0; p->t_run0 = pipe_now();
     p->pending = p->nthreads;
@@ -741,11 +964,27 @@ static int pipe_dispatch(msq_pipeline_t *p, const msq_prepared_t *const *preps, 
 }
 
 int msq_pipeline_run(msq_pipeline_t *p, const msq_prepared_t *const *preps, int nprep, int first, int count, long *hits_out) {
-    return pipe_dispatch(p, preps, nprep, first, count, 0, hits_out);
+    return pipe_dispatch(p, preps, NULL, nprep, first, count, 0, hits_out);
 }
 
 int msq_pipeline_warm(msq_pipeline_t *p, const msq_prepared_t *const *preps, int nprep) {
-    return pipe_dispatch(p, preps, nprep, 0, nprep, 1, NULL);
+    return pipe_dispatch(p, preps, NULL, nprep, 0, nprep, 1, NULL);
+}
+
+/* The same loop from resolved sets: step i FIRST builds the plans of res[(first + i) % nres] (process_termresult for
+ * every (query, shard) of the batch, in the thread that then submits it), so that everything of execute_squery after
+ * the dictionary lookups happens inside the run. */
+int msq_pipeline_run_resolved(msq_pipeline_t *p, const msq_resolved_t *const *res, int nres, int first, int count, long *hits_out) {
+    return pipe_dispatch(p, NULL, res, nres, first, count, 0, hits_out);
+}
+int msq_pipeline_warm_resolved(msq_pipeline_t *p, const msq_resolved_t *const *res, int nres) {
+    return pipe_dispatch(p, NULL, res, nres, 0, nres, 1, NULL);
+}
+/* host milliseconds the last run's threads spent building plans, summed over the threads */
+double msq_pipeline_plan_ms(const msq_pipeline_t *p) {
+    double t = 0;
+    if (p) for (int i = 0; i < p->nthreads; i++) t += p->plan_ms[i];
+    return t;
 }
 
 const char *msq_pipeline_error(const msq_pipeline_t *p) { return p ? p->err : ""; }
@@ -758,6 +997,7 @@ void msq_pipeline_destroy(msq_pipeline_t *p) {
     pthread_mutex_unlock(&p->mu);
     for (int t = 0; t < p->nthreads; t++) pthread_join(p->th[t], NULL);
     pthread_mutex_destroy(&p->mu); pthread_cond_destroy(&p->go); pthread_cond_destroy(&p->done);
+    for (int i = 0; i < 128; i++) msq_prepared_free(p->slot_pp[i]);
     free(p->trace);
     free(p);
 }

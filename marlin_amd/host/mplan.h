@@ -33,22 +33,27 @@ typedef struct mmirror {
 /* pid 0 = all docs, 1..W = wid2bmap, W+1..W+T = twid2bmap, then facetid2bmap, then boolid2bmap */
 int  mmirror_create(const mshard_t *s, int device, mmirror_t **out);
 void mmirror_destroy(mmirror_t *m);
+/* the posting-id scheme alone, no device memory (g and gd stay NULL): enough to build plans, e.g. in CPU-only tests */
+mmirror_t *mmirror_scheme(const mshard_t *s);
+
+/* bump allocator behind the pointers of a plan (or of a whole batch of plans): one reset per batch, no malloc per term */
+typedef struct m_arena m_arena_t;
+m_arena_t *m_arena_new(void);
+void m_arena_reset(m_arena_t *a);
+void m_arena_free(m_arena_t *a);
 
 typedef struct mplan {
     mgpu_plan_t p;
-    /* owned storage behind the pointers in p */
-    uint32_t *term_post[MGPU_MAX_TERMS];
-    mgpu_wid_entry_t *wids;
-    mgpu_fop_t *fops;
-    int fops_cap;
+    mgpu_wid_entry_t *wids;              /* = p.wids: all_wordids (dist != 0xFF) + exact-only entries */
+    m_arena_t *arena;                    /* owned storage behind the pointers in p */
 } mplan_t;
 
 /* lookup_terms + process_termresult + filter leaf resolution for one shard.  Whether the squery is then ranked on a
  * sample (fast-rank, docrank.c:571) is decided on the device from the hit count; the plan carries full_scan and
  * full_scan_threshold for it. */
 int  mplan_build(const mmirror_t *m, const m_query_t *q, int capture, mplan_t *out);
-/* the same after the trie walk: tr[t] = dtrie_lookup_term's result per term (wordids get the words under a twid
- * added), exact_wid[i] = dtrie_lookup_exact's result per query word; q->terms / q->words are not read */
+/* the same after the trie walk: tr[t] = dtrie_lookup_term's result per term, exact_wid[i] = dtrie_lookup_exact's result
+ * per query word; q->terms / q->words are not read, tr is not modified */
 int  mplan_from_terms(const mmirror_t *m, const m_query_t *q, m_termresult_t *tr, const uint32_t *exact_wid,
                       int capture, mplan_t *out);
 void mplan_free(mplan_t *pl);
@@ -80,6 +85,24 @@ int  msq_collect_prepared(mgpu_ctx_t *ctx, const msq_prepared_t *pp, m_sqresult_
 int  msq_prepare_batch_dev(mgpu_ctx_t *ctx, mmirror_t *const *mirrors, int num_shards, const m_query_t *const *queries,
                            int nq, int capture, msq_prepared_t **out);
 void msq_prepared_free(msq_prepared_t *pp);
+/* The two halves of a prepare, apart.  resolve = the DICTIONARY half of lookup_terms for nq queries x num_shards shards
+ * (dtrie_lookup_term per term, dtrie_lookup_exact per word; ctx != NULL runs the typo walks on the device), kept as flat
+ * {twid, (wid, distance) list} records: the termresult_t of dtrie.h:94-97.  plan = everything after it
+ * (process_termresult squery.c:72-118: posting selection, all_wordids, zero-typo sets; exact wids squery.c:159-166; filter
+ * leaves; config), written into a reusable prepared batch whose storage is one arena.  The resolved set must outlive
+ * the prepared batch built from it. */
+typedef struct msq_resolved msq_resolved_t;
+int  msq_resolve_batch(mgpu_ctx_t *ctx, mmirror_t *const *mirrors, int num_shards, const m_query_t *const *queries, int nq,
+                       msq_resolved_t **out);
+void msq_resolved_free(msq_resolved_t *r);
+int  msq_resolved_count(const msq_resolved_t *r);
+msq_prepared_t *msq_prepared_new(void);
+/* inspection (tests): plan i of a prepared batch; term t of pair i of a resolved set -> its (wid, distance) list, *twid;
+ * dtrie_lookup_exact's result for word w of pair i */
+const mgpu_plan_t *msq_prepared_plan(const msq_prepared_t *pp, int i);
+uint32_t msq_resolved_term(const msq_resolved_t *r, int i, int t, uint32_t *twid, const uint32_t **wid, const uint8_t **dist);
+uint32_t msq_resolved_exact(const msq_resolved_t *r, int i, int w);
+int  msq_plan_resolved(const msq_resolved_t *r, int capture, msq_prepared_t *pp);
 /* serving loop: nctx contexts = nctx batches in flight, two contexts per host thread (a thread submits its next
  * batch before it decodes and merges the current one); step i runs batch (first + i) % nprep through
  * submit / collect + form_result (mplan.c) */
@@ -92,6 +115,11 @@ typedef struct msq_pipeline msq_pipeline_t;
 int  msq_pipeline_create(mgpu_ctx_t *const *ctxs, int nctx, msq_pipeline_t **out);
 int  msq_pipeline_warm(msq_pipeline_t *p, const msq_prepared_t *const *preps, int nprep);
 int  msq_pipeline_run(msq_pipeline_t *p, const msq_prepared_t *const *preps, int nprep, int first, int count, long *hits_out);
+/* the serving loop with the plans built INSIDE it: step i = msq_plan_resolved(res[(first + i) % nres]) + submit /
+ * collect + form_result, all in the pipeline's own threads */
+int  msq_pipeline_warm_resolved(msq_pipeline_t *p, const msq_resolved_t *const *res, int nres);
+int  msq_pipeline_run_resolved(msq_pipeline_t *p, const msq_resolved_t *const *res, int nres, int first, int count, long *hits_out);
+double msq_pipeline_plan_ms(const msq_pipeline_t *p);
 const char *msq_pipeline_error(const msq_pipeline_t *p);
 void msq_pipeline_destroy(msq_pipeline_t *p);
 

@@ -1,6 +1,7 @@
 /* mquery.c -- see mquery.h */
 #include "mquery.h"
 #include "mshard.h"
+#include "marlin_gpu.h"
 #include <stdlib.h>
 #include <string.h>
 #include <float.h>
@@ -455,6 +456,7 @@ size_t m_sizeof(int which) {
         case 8: return sizeof(m_word_t);
         case 9: return sizeof(m_term_t);
         case 10: return sizeof(mshard_t);
+        case 11: return sizeof(mgpu_plan_t);
         default: return 0;
     }
 }

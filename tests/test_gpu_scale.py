@@ -108,3 +108,37 @@ def test_more_sparse_lists_than_one_chunk():
         assert got[0]["totalHits"] > 30_000 and got[3]["totalHits"] > 0
     finally:
         eng.close(); ix.close()
+
+
+def test_pipeline_with_plans_built_in_the_loop(zipf):
+    """the serving loop that builds its plans per step (msq_pipeline_run_resolved: process_termresult per batch inside the
+    pipeline's threads) against the batch-at-a-time path: same summed totalHits over several passes, host and device
+    dictionary lookups alike; plans built from a resolved set answer like plans prepared in one go"""
+    lib, ix, eng4 = zipf
+    eng = GpuEngine(ix, num_ctx=4)
+    try:
+        base = [ix.query(dict(jq, fullScan=True)) for jq in queries(lib)]
+        batches = [base[:5], base[3:], base[1:7]]
+        want = [sum(r["totalHits"] for r in eng.search(b)) for b in batches]
+        for dev in (False, True):
+            ress = [eng.resolve(b, device_lookup=dev) for b in batches]
+            eng.warm_pipeline_resolved(ress, 4)
+            hits, plan_ms = eng.run_pipeline_resolved(ress, 1, 7, 4)
+            assert hits == sum(want[(1 + i) % 3] for i in range(7)), dev
+            assert plan_ms > 0
+            # a prepared batch planned from the resolved set, full comparison with the oracle
+            prep = eng.plan_resolved(ress[0], capture=3)
+            outs = eng.execute_prepared(prep)
+            from marlin_amd.engine import assemble, shard_results_to_py
+            ns = ix.num_shards
+            for i, pq in enumerate(batches[0]):
+                sub = (ffi.SqResult * ns).from_address(C.addressof(outs) + i * ns * C.sizeof(ffi.SqResult))
+                g = assemble(ix, pq, sub)
+                g["_shards"] = shard_results_to_py(ix, pq, sub)
+                compare_results(g, orc_py.search(ix, pq, flags=3), ctx=pq.jq)
+            eng.free_raw(outs)
+            eng.free_prepared(prep)
+            for r in ress:
+                eng.free_resolved(r)
+    finally:
+        eng.close()
