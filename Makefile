@@ -23,6 +23,13 @@ marlin_amd/lib/libmarlin_gpu.so: $(GPU_SRC) $(GPU_HDR)
 	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Iinclude -Imarlin_amd/csrc \
 	    -o $@ $(GPU_SRC)
 
+# the same library with the checked accessors of the rank / doc-processing kernels compiled in (mgpu_kernels.hip, CK):
+# `make gpu-checked` overwrites libmarlin_gpu.so; run the GPU suite on it, then `make -B gpu` for the product build
+gpu-checked: $(GPU_SRC) $(GPU_HDR)
+	@mkdir -p marlin_amd/lib
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DMGPU_CHECKED -Iinclude -Imarlin_amd/csrc \
+	    -o marlin_amd/lib/libmarlin_gpu.so $(GPU_SRC)
+
 marlin_amd/lib/libmarlin_host.so: $(HOST_SRC) $(HOST_HDR) marlin_amd/lib/libmarlin_gpu.so
 	@mkdir -p marlin_amd/lib
 	$(CC) $(CFLAGS) -shared -Iinclude -o $@ $(HOST_SRC) -Lmarlin_amd/lib -lmarlin_gpu \
@@ -43,6 +50,18 @@ oracle/_ref/libmarlin_ref.so:
 	    $(REF)/src/main/bmap.c $(REF)/src/main/cont.c $(REF)/src/main/sort.c \
 	    $(REF)/src/main/hashtable.c $(REF)/src/utils/farmhash-c.c -o $@
 
+# The reference's index-writing code (sindex.c, compiled where it lies by oracle/ref_seam.c's #include) over the
+# reference's own LMDB (mdb.c, midl.c): writes docid2data blobs and num_dbi entries for tests/golden/docdata_cases.json.
+# Symbols of the reference the program never calls stay unresolved.  Build container only.
+REF_INC = -I$(REF)/src/inc -I$(REF)/src/main -I$(REF)/src/utils -I$(REF)/src/analyzer \
+          -I$(REF)/deps/jansson/src -I$(REF)/deps/jansson/android -I$(REF)/deps/h2o/include -I$(REF)/deps/lmdb \
+          -I$(REF)/deps/utf8proc -I$(REF)/deps
+ref-seam: oracle/_ref/ref_seam
+oracle/_ref/ref_seam: oracle/ref_seam.c
+	@mkdir -p oracle/_ref
+	$(CC) -std=gnu99 -O1 -g -w -D_GNU_SOURCE -DH2O_USE_LIBUV=0 $(REF_INC) oracle/ref_seam.c \
+	    $(REF)/deps/lmdb/mdb.c $(REF)/deps/lmdb/midl.c $(REF)/src/utils/mlog.c -Wl,--unresolved-symbols=ignore-all -o $@ -lpthread -lm
+
 # The drop-in replacement for the reference's squery.c, compiled against the reference's own headers (same include
 # paths as `ref`).  Build container only; the object never travels and nothing links it here: the check is that it
 # compiles without warnings and exports execute_squery / sqresult_free (tests/test_shim.py).
@@ -57,4 +76,4 @@ shim/_build/squery_gpu.o: shim/squery_gpu.c $(HOST_HDR)
 clean:
 	rm -f marlin_amd/lib/*.so oracle/liborc.so oracle/_ref/*.so shim/_build/*.o
 
-.PHONY: all gpu host oracle ref shim clean
+.PHONY: all gpu gpu-checked host oracle ref ref-seam shim clean

@@ -25,7 +25,7 @@ void mgk_scatter(hipStream_t st, const ScatterItem *items, uint32_t nitems);
 void mgk_formula(hipStream_t st, const SqDev *sqs, const uint32_t *blob, uint32_t max_nblk, uint32_t nsq,
                  uint2 *tile_list, uint32_t *tile_count, uint32_t tile_cap, uint32_t *fh_list, uint32_t *fh_count, uint32_t fh_cap);
 void mgk_rank(hipStream_t st, const SqDev *sqs, const uint32_t *blob, uint32_t max_n, uint32_t nsq,
-              uint32_t max_tab_slots, const uint2 *tile_list, const uint32_t *tile_count, uint32_t tile_cap,
+              uint32_t max_tab_slots, int with_len, const uint2 *tile_list, const uint32_t *tile_count, uint32_t tile_cap,
               unsigned long long *pool, uint32_t *pool_used, uint64_t pool_cap);
 void mgk_docproc(hipStream_t st, const SqDev *sqs, uint32_t nsq, const uint2 *tile_list, const uint32_t *tile_count,
                  uint32_t tile_cap, uint32_t lds_bins, int pre);
@@ -82,6 +82,7 @@ struct mgpu_shard {
     std::vector<uint64_t> post_off;     // sparse CSR offsets (per pid)
     std::vector<uint32_t> post_card;    // docs per posting (bounds the hit count of a plan)
     std::vector<uint32_t> post_winbase; // per pid: base into post_win, or ~0 (dense, empty or short posting)
+    bool rec_len_ok = false;            // the rank kernel may carry a record's length in the top byte of its docid word
     uint32_t fac_single = 0;            // bit f: every document has <= 1 value in facet field f, and every facet section is staged whole by the rank kernel
     uint64_t np_n[MGPU_MAX_FIELDS];
     uint32_t np_multi = 0;              // bit i: some document appears more than once in num_dbi[i] (a list-valued field)
@@ -321,6 +322,7 @@ static int shard_create_impl(int device, const mgpu_shard_desc_t *d, mgpu_shard_
         dw_off[N] = (uint32_t)dw.size(); pp_off[N] = (uint32_t)pp.size();
         dw_off[0] = 0; pp_off[0] = 0;
         s->avg_dw = N > 1 ? (double)dw.size() / (double)(N - 1) : 0.0;
+        sd.dw_len = (uint32_t)dw.size(); sd.pp_len = (uint32_t)pp.size();
         if ((rc = upload(s, dw_off, &sd.dw_off)) || (rc = upload(s, dw, &sd.dw)) ||
             (rc = upload(s, pp_off, &sd.pp_off)) || (rc = upload(s, pp, &sd.pp))) { mgpu_shard_destroy(s); return rc; }
         for (int i = 0; i < d->num_numbers; i++)
@@ -353,31 +355,55 @@ static int shard_create_impl(int device, const mgpu_shard_desc_t *d, mgpu_shard_
                 for (int f = 0; f < d->num_facets; f++) b += 4 + 4 * (fa_off[f][doc + 1] - fa_off[f][doc]);
                 return (b + 7) & ~7u;
             };
+            // The facet area has ONE size per shard (what 90 % of the documents need, at most 64 B), so that the docword
+            // entries of every record start at the same 8-byte slot `ws`: the rank kernel's lanes know their role without
+            // reading a header.  A document whose facet section is larger keeps it in the per-field CSR (facets_in = 0).
+            uint32_t FA = 0;
+            if (d->num_facets > 0 && N > 1) {
+                std::vector<uint32_t> fh(9, 0);                       // facet bytes in units of 8, 8 = "more than 56"
+                for (uint32_t doc = 1; doc < N; doc++) fh[std::min<uint32_t>(facet_bytes(doc) / 8, 8)]++;
+                uint32_t acc = 0, u = 8;
+                for (uint32_t c = 0; c <= 8; c++) { acc += fh[c]; if ((uint64_t)acc * 10 >= (uint64_t)(N - 1) * 9) { u = c; break; } }
+                FA = std::min<uint32_t>(u, 8) * 8;
+            }
             // stride: the smallest multiple of 128 B that holds 90 % of the documents whole (<= 512)
             std::vector<uint32_t> hist(5, 0);
             for (uint32_t doc = 1; doc < N; doc++) {
-                uint32_t need = hdr + facet_bytes(doc) + 8 * (dw_off[doc + 1] - dw_off[doc]);
+                uint32_t need = hdr + FA + 8 * (dw_off[doc + 1] - dw_off[doc]);
                 uint32_t c = (need + 127) / 128; if (c > 4) c = 4;
                 hist[c]++;
             }
             uint32_t S = 512, acc = 0;
             for (uint32_t c = 1; c <= 4; c++) { acc += hist[c]; if ((uint64_t)acc * 10 >= (uint64_t)(N - 1) * 9) { S = c * 128; break; } }
-            std::vector<uint32_t> rec((size_t)N * (S / 4), 0);
+            if (hdr + FA + 8 > S) { FA = 0; }                          // degenerate schema: no facet area
+            const uint32_t ws_c = (hdr + FA) / 8;
+            const uint64_t rec_u32 = (uint64_t)N * (S / 4);
+            std::vector<uint32_t> rec((size_t)N * (S / 4) + pp.size(), 0);
+            if (!pp.empty()) memcpy(rec.data() + rec_u32, pp.data(), pp.size() * sizeof(uint32_t));
+            // bytes of each record that hold anything, in 16-byte units (the lanes beyond it load nothing); only when
+            // docids fit 24 bits, because the kernel carries the length in the top byte of its docid word
+            std::vector<uint8_t> rlen(N, 0);
+            // (MGPU_NO_POOLIN / MGPU_NO_RECLEN: measurement switches, read when a mirror is built)
+            // Word 1 of a record is the u32 index of the document's positions in ONE array: the records, then a copy of
+            // the shard's position pool.  Positions that fit behind a document's docwords are placed there (index into the
+            // record itself), the others are found in the copy; the kernel adds the index to one base pointer either way.
+            if (rec_u32 + pp.size() >= 0xFFFFFFFFull) { mgpu_shard_destroy(s); return fail(MGPU_E_LIMIT, "records + positions beyond 2^32 words in one shard"); }
+            const bool pool_in = !getenv("MGPU_NO_POOLIN");
             bool all_staged = d->num_facets > 0;
+            uint64_t n_pool_in = 0, n_full = 0;
             for (uint32_t doc = 1; doc < N; doc++) {
                 uint32_t *r = rec.data() + (size_t)doc * (S / 4);
                 const uint32_t nwords = dw_off[doc + 1] - dw_off[doc];
-                uint32_t fb = facet_bytes(doc);
-                const bool facets_in = d->num_facets > 0 && hdr + fb <= S / 2;
+                const uint32_t fb = facet_bytes(doc);
+                const bool facets_in = d->num_facets > 0 && fb <= FA;
                 if (!facets_in || fb > 4 * MG_PCAP) all_staged = false;
-                if (!facets_in) fb = 0;
-                const uint32_t ws = (hdr + fb) / 8;
-                uint32_t nin = (S - (hdr + fb)) / 8;
+                uint32_t nin = (S - 8 * ws_c) / 8;
                 if (nin > nwords) nin = nwords;
+                uint32_t used = 8 * (ws_c + nin);                     // bytes
                 r[0] = (nwords > 0xFFFF ? 0xFFFFu : nwords) | (nin << 16);
-                r[1] = pp_off[doc];
+                r[1] = (uint32_t)(rec_u32 + pp_off[doc]);
                 r[2] = dw_off[doc] + nin;
-                r[3] = (uint32_t)nnum_in | ((facets_in ? 1u : 0u) << 8) | (ws << 16);
+                r[3] = (uint32_t)nnum_in | ((facets_in ? 1u : 0u) << 8) | (ws_c << 16);
                 for (int i = 0; i < nnum_in; i++) memcpy(&r[4 + 2 * i], &cols[i][doc], 8);
                 if (facets_in) {
                     uint32_t *fp = r + hdr / 4;
@@ -387,9 +413,24 @@ static int shard_create_impl(int device, const mgpu_shard_desc_t *d, mgpu_shard_
                         for (uint32_t j = a; j < b; j++) *fp++ = fa_ords[f][j];
                     }
                 }
-                for (uint32_t j = 0; j < nin; j++) { r[2 * (ws + j)] = dw[dw_off[doc] + j].x; r[2 * (ws + j) + 1] = dw[dw_off[doc] + j].y; }
+                for (uint32_t j = 0; j < nin; j++) { r[2 * (ws_c + j)] = dw[dw_off[doc] + j].x; r[2 * (ws_c + j) + 1] = dw[dw_off[doc] + j].y; }
+                // the document's decoded positions right behind its docwords when everything fits: the rank kernel's
+                // position reads then land in the lines it has just fetched (the lanes that hold them do not take them
+                // for docword entries: the header's entry count says where the entries end)
+                const uint32_t npos = pp_off[doc + 1] - pp_off[doc];
+                if (pool_in && nin == nwords && npos > 0 && used + 4 * npos <= S) {
+                    for (uint32_t j = 0; j < npos; j++) r[used / 4 + j] = pp[pp_off[doc] + j];
+                    r[1] = (uint32_t)((size_t)doc * (S / 4) + used / 4);
+                    used += 4 * npos;
+                    n_pool_in++;
+                }
+                n_full += nin == nwords;
+                rlen[doc] = (uint8_t)((used + 15) / 16);
             }
             if ((rc = upload(s, rec, &sd.rec))) { mgpu_shard_destroy(s); return rc; }
+            { const uint8_t *pl; if ((rc = upload(s, rlen, &pl))) { mgpu_shard_destroy(s); return rc; } sd.rec_len = pl; }
+            s->rec_len_ok = N <= (1u << 24) && !getenv("MGPU_NO_RECLEN");
+            sd.rec_ws = ws_c; sd.rec_words = (uint32_t)rec.size();
             if (all_staged)
                 for (int f = 0; f < d->num_facets; f++) {
                     bool single = true;
@@ -953,12 +994,15 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
             if (cap <= MG_LDS_HASH) max_tab = std::max(max_tab, cap);
             size_t base = blob.size();
             blob.resize(base + (size_t)cap * 2, 0);
+            // an empty slot's key is MG_WID_EMPTY, not 0: the zero padding of a record is probed like a word and must
+            // meet "empty or another key", never "equal"
+            for (uint32_t j = 0; j < cap; j++) blob[base + (size_t)j * 2] = MG_WID_EMPTY;
             for (uint32_t j = 0; j < p.num_wids; j++) {
                 const mgpu_wid_entry_t &e = p.wids[j];
-                if (e.wid == 0) return fail(MGPU_E_ARG, "wid 0 in wid table");
+                if (e.wid == 0 || e.wid >= 0x80000000u) return fail(MGPU_E_ARG, "wid 0 or above 2^31 in wid table");
                 uint32_t hsh = (uint32_t)((uint64_t)(e.wid & 0xFFFFFFu) * MG_WID_HASH_K); hsh ^= hsh >> 15;      // = hash_wid of the kernels
                 uint32_t slot = hsh & (cap - 1);
-                while (blob[base + slot * 2] != 0 && blob[base + slot * 2] != e.wid) slot = (slot + 1) & (cap - 1);
+                while (blob[base + slot * 2] != MG_WID_EMPTY && blob[base + slot * 2] != e.wid) slot = (slot + 1) & (cap - 1);
                 blob[base + slot * 2] = e.wid;
                 blob[base + slot * 2 + 1] = (uint32_t)e.dist | ((uint32_t)e.mterm << 8) | ((uint32_t)e.exact_mask << 16);
             }
@@ -1328,7 +1372,9 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
     }
     mark();
     tick();
-    mgk_rank(st, d_sq, d_blob, max_N, (uint32_t)n, max_tab, d_tiles, d_tilecnt, (uint32_t)tile_cap, c->pool, c->pool_used, c->pool_cap);
+    bool rank_len = true;                  // every shard of the batch lets the rank kernel pack record lengths
+    for (int i = 0; i < n; i++) rank_len = rank_len && shards[i]->rec_len_ok;
+    mgk_rank(st, d_sq, d_blob, max_N, (uint32_t)n, max_tab, rank_len ? 1 : 0, d_tiles, d_tilecnt, (uint32_t)tile_cap, c->pool, c->pool_used, c->pool_cap);
     mark();
     mgk_docproc(st, d_sq, (uint32_t)n, d_tiles, d_tilecnt, (uint32_t)tile_cap, max_lds_bins, 0);
     mark();
@@ -1414,6 +1460,11 @@ static int execute_end(mgpu_ctx_t *c, mgpu_sqout_t *outs, bool *completed) {
         const bool fast = q.fast_eligible && hdr->fast_flag;
         o.num_hits = fast ? hdr->total_hits : hdr->num_hits;
         o.fast_rank = fast ? 1 : 0;
+        if (hdr->err >= 0x40000000u) {
+            // a checked accessor refused an access (mgpu_kernels.hip: CK sites)
+            char msg[96]; snprintf(msg, sizeof(msg), "checked accessor: site %u, index (low 24 bits) %u", (hdr->err >> 24) & 0x3Fu, hdr->err & 0xFFFFFFu);
+            o.status = MGPU_E_HIP; worst = o.status; g_err = msg; continue;
+        }
         if (hdr->err) { o.status = -(int)hdr->err; worst = o.status; g_err = hdr->err == (uint32_t)(-MGPU_E_LIMIT) ? (fast ? "fast-rank: the sample outgrows the reference's rank buffer, or rank_by has several values per document" : "hit count above the planned bound")
                                                                      : hdr->err == (uint32_t)(-MGPU_E_UNSUPPORTED) ? "fast-rank with a cardinality aggregation (the reference dereferences NULL there) or without facet_pid_base"
                                                                      : "device reported an error (position scratch pool exhausted)"; continue; }

@@ -576,6 +576,24 @@ __global__ __launch_bounds__(MG_BLOCK) void k_facet_recount(const SqDev *sqs, co
     }
 }
 
+// ------------------------------------------------------------------ checked accessors
+// MGPU_CHECKED build (make gpu-checked): every global access of the rank / doc-processing kernels whose index is DATA
+// (a docid from a hit list, a header word of a record, an ordinal or an offset staged through LDS) is compared with the
+// extent the mirror recorded; the first class of violation is reported through the squery's err word
+// (0x40000000 | site << 24 | low 24 bits of the index -> MGPU_E_HIP "checked accessor") and the access is NOT made.
+// Kernel edits run as a checked build over the whole GPU suite before they run unchecked.  The ordinal guards
+// in front of the histogram atomics (sites 4 and 9) are permanent: one compare each.
+__device__ __forceinline__ bool mg_ck_always(uint32_t *err, uint32_t site, u64 idx, u64 ext) {
+    if (idx < ext) return true;
+    atomicMax(err, 0x40000000u | (site << 24) | (uint32_t)(idx & 0xFFFFFFu));
+    return false;
+}
+#ifdef MGPU_CHECKED
+#define CK(site, idx, ext) mg_ck_always(sp->err, (site), (u64)(idx), (u64)(ext))
+#else
+#define CK(site, idx, ext) true
+#endif
+
 // ------------------------------------------------------------------ ranking
 struct RankOut { uint32_t typos, prox, field, pos, exact; };
 
@@ -589,7 +607,7 @@ __device__ __forceinline__ bool probe_wid(const uint2 *htab, uint32_t hmask, uin
     for (uint32_t h = hash_wid(wid) & hmask;; h = (h + 1) & hmask) {
         const uint2 s = htab[h];
         if (s.x == wid) { val = s.y; return true; }
-        if (s.x == 0) return false;
+        if (s.x == MG_WID_EMPTY) return false;
     }
 }
 
@@ -828,10 +846,14 @@ __device__ __forceinline__ void wave_append(bool pred, uint32_t v, uint32_t *lis
 }
 
 extern __shared__ uint2 dyn_tab[];
+// LEN: every shard of the batch has docids below 2^24, so a record's length (ShardDev::rec_len, 16-byte units) rides in
+// the top byte of the tile's docid words and the lanes beyond it load nothing
+template <bool LEN>
 __global__ __launch_bounds__(MG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_rank_tile(const SqDev *sqs, const uint32_t *blob,
                                                         const uint2 *tile_list, const uint32_t *tile_count) {
     __shared__ uint32_t s_doc[MG_BLOCK], s_pbase[MG_BLOCK], s_cnt[MG_BLOCK], s_np[MG_BLOCK];
     __shared__ double s_val[MG_BLOCK];
+    __shared__ uint32_t s_nord[MGPU_MAX_FIELDS];      // ordinals per facet field of the squery in hand (the ordinal guard's extents)
     __shared__ uint2 s_match[MG_BLOCK * MG_MCAP];
     __shared__ uint32_t s_pairs[MG_BLOCK * MG_PCAP];
     const uint32_t ntiles = *tile_count;
@@ -843,6 +865,7 @@ __global__ __launch_bounds__(MG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
     const uint32_t per = (ntiles + gridDim.x - 1) / gridDim.x;
     const uint32_t w_end = (blockIdx.x + 1) * per < ntiles ? (blockIdx.x + 1) * per : ntiles;
     uint32_t tab_of = 0xFFFFFFFFu;                   // squery whose table dyn_tab holds
+    uint32_t nord_of = 0xFFFFFFFFu;                  // squery whose field sizes s_nord holds
     for (uint32_t w = blockIdx.x * per; w < w_end; w++) {
         DBG_T(t0);
         // the work item is the same for every lane: say so, so that the descriptor is read with scalar loads
@@ -859,8 +882,8 @@ __global__ __launch_bounds__(MG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
         const int rb = sp->rank_by;
         const uint32_t rec_nnum = sp->sh.rec_nnum, rec_stride = sp->sh.rec_stride;
         const uint4 *rec = (const uint4 *)sp->sh.rec;
+        const uint8_t *rec_len = sp->sh.rec_len;
         const uint2 *dw = sp->sh.dw;
-        const uint32_t *pp = sp->sh.pp;
         const int nw = sp->num_words, nt = sp->num_terms;
         const uint32_t exact_present = sp->exact_present;
         u64 *p_key_hi = (u64 *)sp->key_hi, *p_key_lo = (u64 *)sp->key_lo, *p_key_andor = (u64 *)sp->key_andor;
@@ -870,6 +893,9 @@ __global__ __launch_bounds__(MG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
         const int fac_here = sp->fac_in_rank;
         const uint32_t fac_mask = sp->hist_mask, fdirect = sp->fdirect_mask, fhash = sp->fhash_mask;
         const int nfac = sp->sh.num_facets;
+#ifdef MGPU_CHECKED
+        const uint32_t x_N = sp->sh.N, x_dw = sp->sh.dw_len, x_cap = sp->hit_cap, x_rec = sp->sh.rec_words;
+#endif
         if (do_rank < 0) continue;                   // no hits requested: nobody reads the keys
         const uint32_t M = *p_num_hits;
         const uint2 *gtab = (const uint2 *)(blob + hash_off);
@@ -882,10 +908,19 @@ __global__ __launch_bounds__(MG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                 for (uint32_t i = tid; i <= hmask; i += MG_BLOCK) dyn_tab[i] = gtab[i];
                 tab_of = item.x;
             }
-            s_doc[tid] = docid; s_cnt[tid] = 0; s_np[tid] = 0;
+            if (fac_here && nord_of != item.x) {           // once per run of tiles, with the loads of the tile's first step
+                if (tid < MGPU_MAX_FIELDS) s_nord[tid] = sp->sh.fa_nord[tid];
+                nord_of = item.x;
+            }
+            {
+                uint32_t dl = docid;
+                if (LEN && valid && CK(1, docid, x_N)) dl = docid | ((uint32_t)rec_len[docid] << 24);
+                s_doc[tid] = dl; s_cnt[tid] = 0; s_np[tid] = 0;
+            }
             __syncthreads();
             DBG_T(t1); DBG_ADD(0, t0, t1);
             const uint32_t S16 = rec_stride >> 4;                  // uint4 per record
+            const uint32_t dmask = LEN ? 0xFFFFFFu : 0xFFFFFFFFu;
             // group g owns documents 16g .. 16g+15 of the tile and reads each record as ONE coalesced
             // load of 16 bytes per lane (256 B); eight records are in flight per lane at a time.
             // two explicit probe paths: through a runtime-selected pointer the compiler would emit
@@ -909,15 +944,16 @@ __global__ __launch_bounds__(MG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                 for (h = (h + 1) & hmask;; h = (h + 1) & hmask) {
                     const uint2 e = dyn_tab[h];
                     if (e.x == wid) { record(d, e.y, info); return; }
-                    if (e.x == 0) return;
+                    if (e.x == MG_WID_EMPTY) return;
                 }
             };
             for (int half = 0; half < 2; half++) {
                 uint4 v[8];
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
-                    const uint32_t doc = s_doc[grp * 16 + half * 8 + k];
-                    v[k] = (doc != 0xFFFFFFFFu && gl < S16) ? rec[(size_t)doc * S16 + gl] : make_uint4(0u, 0u, 0u, 0u);
+                    const uint32_t dl = s_doc[grp * 16 + half * 8 + k];
+                    const uint32_t doc = dl & dmask, len16 = LEN ? (dl >> 24) : S16;
+                    v[k] = (dl != 0xFFFFFFFFu && gl < len16 && gl < S16 && CK(1, doc, x_N)) ? rec[(size_t)doc * S16 + gl] : make_uint4(0u, 0u, 0u, 0u);
                 }
                 // headers (lane 0 of the group holds them), rank value, and which of the lane's two 8-byte
                 // slots are docword entries
@@ -979,8 +1015,8 @@ __global__ __launch_bounds__(MG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                                 if (ma && ra < MG_MCAP) s_match[ra * MG_BLOCK + d] = make_uint2(pa[k].y, e.y);
                                 if (mb && rb2 < MG_MCAP) s_match[rb2 * MG_BLOCK + d] = make_uint2(pb[k].y, e.w);
                                 if (gl == 0) s_cnt[d] = (uint32_t)__popc(ga) + (uint32_t)__popc(gb);
-                                if (use_a && !ma && pa[k].x != 0) take_from(d, e.x, e.y, hash_wid(e.x) & hmask);
-                                if (use_b && !mb && pb[k].x != 0) take_from(d, e.z, e.w, hash_wid(e.z) & hmask);
+                                if (use_a && !ma && pa[k].x != MG_WID_EMPTY) take_from(d, e.x, e.y, hash_wid(e.x) & hmask);
+                                if (use_b && !mb && pb[k].x != MG_WID_EMPTY) take_from(d, e.z, e.w, hash_wid(e.z) & hmask);
                             }
                         }
                     } else {
@@ -997,15 +1033,17 @@ __global__ __launch_bounds__(MG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                         for (int k = 0; k < 8; k++) {
                             if (!((tail >> k) & 1u)) continue;
                             const uint32_t d = grp * 16 + half * 8 + k;
-                            const uint32_t doc = s_doc[d];
+                            const uint32_t doc = s_doc[d] & dmask;
                             const uint32_t h0 = __shfl(v[k].x, 0, 16), h2 = __shfl(v[k].z, 0, 16), h3 = __shfl(v[k].w, 0, 16);
                             const uint32_t nin = h0 >> 16, ws = h3 >> 16, nwords_k = h0 & 0xFFFFu;
                             for (uint32_t c = 16 + gl; c < S16; c += 16) {
+                                if (!CK(1, doc, x_N)) break;
                                 const uint4 x = rec[(size_t)doc * S16 + c];
                                 if (2 * c >= ws && 2 * c < ws + nin) take(d, x.x, x.y);
                                 if (2 * c + 1 >= ws && 2 * c + 1 < ws + nin) take(d, x.z, x.w);
                             }
                             for (uint32_t j = nin + gl; j < nwords_k; j += 16) {
+                                if (!CK(2, (u64)h2 + (j - nin), x_dw)) break;
                                 const uint2 w2 = dw[h2 + (j - nin)];
                                 take(d, w2.x, w2.y);
                             }
@@ -1033,7 +1071,10 @@ __global__ __launch_bounds__(MG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                             else if (cnt == 1 && pos + 1 < MG_PCAP) code = s_pairs[(pos + 1) * MG_BLOCK + tid];
                             pos += 1 + cnt;
                         } else staged_ok = false;
-                        if ((hist_mask >> f) & 1u) sp->fac_ord[f][t] = code;
+                        // the ordinal came through LDS staging and indexes histograms and ordinal -> id tables from here
+                        // on: one that is not an ordinal of the field is reported, never used (permanent guard)
+                        if (code < MG_FAC_LOOKUP && code >= s_nord[f]) { mg_ck_always(sp->err, 4, code, s_nord[f]); code = MG_FAC_NONE; }
+                        if (((hist_mask >> f) & 1u) && CK(5, t, x_cap)) sp->fac_ord[f][t] = code;
                         // directly counted field: one fire-and-forget atomic, nothing waits for it
                         // (unless the select stage counts the field by hashing the ordinals: few enough hits)
                         if (((fdirect >> f) & 1u) && code < MG_FAC_LOOKUP && !(((fhash >> f) & 1u) && M <= MG_FHASH_MAX_M))
@@ -1055,7 +1096,11 @@ __global__ __launch_bounds__(MG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                 const uint32_t cnt = s_cnt[tid];
                 if (cnt > MG_MCAP) ok = false;
                 else {
-                    const uint32_t *pdoc = pp + s_pbase[tid];
+                    // the document's positions: one index into the records-then-pool array, wherever they lie
+                    const uint32_t *pdoc = (const uint32_t *)rec + s_pbase[tid];
+#ifdef MGPU_CHECKED
+                    const u64 x_pbase = s_pbase[tid], x_pext = x_rec;
+#endif
                     uint32_t p0[MG_MCAP], p1[MG_MCAP], p2[MG_MCAP];
 #pragma unroll
                     for (int r = 0; r < MG_MCAP; r++) {
@@ -1066,8 +1111,9 @@ __global__ __launch_bounds__(MG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                             if ((m.x & 0xFF) != 0xFF) {                       // exact-only entries need no positions
                                 if (info & 1u) p0[r] = info_first_inline(info);
                                 else {
-                                    const uint32_t pc = (info >> 1) & 0xFFu;
+                                    uint32_t pc = (info >> 1) & 0xFFu;
                                     const uint32_t *pd = pdoc + (info >> 9);
+                                    if (pc > 0 && !CK(3, x_pbase + (info >> 9) + pc - 1, x_pext)) pc = 0;
                                     if (pc > 0) p0[r] = pd[0];
                                     if (nw > 1 && pc > 1) p1[r] = pd[1];
                                     if (nw > 1 && pc > 2) p2[r] = pd[2];
@@ -1092,6 +1138,7 @@ __global__ __launch_bounds__(MG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                         if ((uint32_t)st.np + per * pc > MG_PCAP) { st.ovf = true; continue; }
                         const uint32_t *pd = pdoc + (info >> 9);
                         for (uint32_t j = 0; j < pc; j++) {
+                            if (j > 2 && !CK(3, x_pbase + (info >> 9) + j, x_pext)) break;
                             const uint32_t pv = (j == 0) ? p0[r] : (j == 1) ? p1[r] : (j == 2) ? p2[r] : pd[j];
                             if (keep_a) ps.set(st.np++, ((uint32_t)slot_a << 24) | pv);
                             if (slot_b >= 0) ps.set(st.np++, ((uint32_t)slot_b << 24) | pv);
@@ -1099,12 +1146,12 @@ __global__ __launch_bounds__(MG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                     }
                     if (st.ovf) ok = false; else rank_finish(st, nw, exact_present, ps, ro);
                 }
-                if (!ok) p_ovf_list[atomicAdd(p_ovf_cnt, 1u)] = t;
+                if (!ok) { const uint32_t oi = atomicAdd(p_ovf_cnt, 1u); if (CK(6, oi, x_cap)) p_ovf_list[oi] = t; }
             }
             if (ok) {
                 u64 hi, lo;
-                build_key(kl, ro, val_in_rec ? s_val[tid] : (rb >= 0 ? col[docid] : 0.0), hi, lo);
-                p_key_hi[t] = hi; p_key_lo[t] = lo;
+                build_key(kl, ro, val_in_rec ? s_val[tid] : ((rb >= 0 && CK(7, docid, x_N)) ? col[docid] : 0.0), hi, lo);
+                if (CK(8, t, x_cap)) { p_key_hi[t] = hi; p_key_lo[t] = lo; }
                 a = hi; b = lo; na = ~hi; nb = ~lo;
             }
         }
@@ -1205,6 +1252,7 @@ __global__ __launch_bounds__(MG_BLOCK) void k_docproc(const SqDev *sqs, const ui
                 const uint32_t code = have_ords ? ords[i] : MG_FAC_LOOKUP;
                 if (code == MG_FAC_NONE) continue;
                 if (code != MG_FAC_LOOKUP) {
+                    if (!mg_ck_always(sq.err, 9, code, nord)) continue;              // permanent guard: see k_rank_tile, site 4
                     if (use_lds) atomicAdd(&hist[code], 1u);
                     else wave_append(atomicAdd(&gh[code], 1u) == 0, code, tl, tn);
                     continue;
@@ -2458,15 +2506,15 @@ void mgk_facet_recount(hipStream_t st, const SqDev *sqs, const void *jobs, uint3
     hipLaunchKernelGGL(k_facet_recount, dim3(njobs), dim3(MG_BLOCK), 0, st, sqs, (const RecountJob *)jobs);
 }
 void mgk_rank(hipStream_t st, const SqDev *sqs, const uint32_t *blob, uint32_t max_n, uint32_t nsq,
-              uint32_t max_tab_slots, const uint2 *tile_list, const uint32_t *tile_count, uint32_t tile_cap,
+              uint32_t max_tab_slots, int with_len, const uint2 *tile_list, const uint32_t *tile_count, uint32_t tile_cap,
               unsigned long long *pool, uint32_t *pool_used, uint64_t pool_cap) {
     if (max_tab_slots > MG_LDS_HASH) max_tab_slots = MG_LDS_HASH;
     // workgroups of the persistent grid: MGPU_RANK_GRID overrides the default (a tuning knob; any value >= 1 is correct)
     static const uint32_t grid_env = [] { const char *e = getenv("MGPU_RANK_GRID"); long v = e ? atol(e) : 0; return (uint32_t)(v > 0 && v <= 65535 ? v : 0); }();
     uint32_t grid = grid_env ? grid_env : worklist_grid(tile_cap);
     if (grid > tile_cap && tile_cap) grid = tile_cap;
-    hipLaunchKernelGGL(k_rank_tile, dim3(grid), dim3(MG_BLOCK), (size_t)max_tab_slots * sizeof(uint2), st,
-                       sqs, blob, tile_list, tile_count);
+    if (with_len) hipLaunchKernelGGL(k_rank_tile<true>, dim3(grid), dim3(MG_BLOCK), (size_t)max_tab_slots * sizeof(uint2), st, sqs, blob, tile_list, tile_count);
+    else hipLaunchKernelGGL(k_rank_tile<false>, dim3(grid), dim3(MG_BLOCK), (size_t)max_tab_slots * sizeof(uint2), st, sqs, blob, tile_list, tile_count);
     uint32_t gy = (max_n + MG_BLOCK - 1) / MG_BLOCK;
     uint32_t cap = 4096 / nsq; if (cap < 4) cap = 4;
     if (gy > cap) gy = cap;

@@ -19,6 +19,7 @@
 #define MG_SCATTER_CHUNK 2048        // docids per scatter work item
 #define MG_LDS_HASH     4096         // wid table slots staged in LDS (32 KiB)
 #define MG_WID_HASH_K   0x9E3779u    // wid table hash: low 32 bits of (wid & 0xFFFFFF) * K, folded with >> 15
+#define MG_WID_EMPTY    0xFFFFFFFFu  // key of an empty wid table slot
 #define MG_LDS_HIST     8192         // facet bins privatised in LDS (32 KiB)
 
 // Device view of one shard mirror.
@@ -41,8 +42,13 @@ struct ShardDev {
     const uint32_t *pp;
     // doc-major records: one aligned record of rec_stride bytes per docid:
     //   u32 nwords | nin << 16 ; u32 pbase ; u32 ovf (= dw_off[doc] + nin) ; u32 nnum_in | facets_in << 8 | ws << 16
-    //   f64 x nnum_in ; [facet section: per field u32 count + ordinals] ; from 8-byte slot ws: nin x {wid, info}
+    //   f64 x nnum_in ; [facet area of a shard-constant size: per field u32 count + ordinals] ; from 8-byte slot ws
+    //   (= rec_ws, the same in every record): nin x {wid, info} ; then, when everything fits, the document's decoded
+    //   positions with bit 31 set (pbase = 0x80000000 | their u32 index in rec) ; zero padding
     const uint32_t *rec;
+    const uint8_t  *rec_len;         // [N] 16-byte units of each record that hold anything, or NULL (docids beyond 24 bits)
+    uint32_t rec_ws;                 // first docword slot of every record
+    uint32_t rec_words;              // u32 words in rec (checked accessors)
     uint32_t rec_stride;             // bytes: 128, 256, 384 or 512
     uint32_t rec_nnum;               // numbers held in every record (all of them when num_numbers <= 4, else 0)
     // facets
@@ -57,6 +63,8 @@ struct ShardDev {
     // idnum2dbl (sindex.c:528-565): bit g of grp_has[i] = some document of docids [1000 g, 1000 g + 1000) indexed a
     // number of field i, i.e. the group's array exists (what get_num_value reads in fast-rank mode)
     const uint64_t *grp_has[MGPU_MAX_FIELDS];
+    // extents of the data-indexed arrays (checked accessors, mgpu_kernels.hip): entries of dw, of pp
+    uint32_t dw_len, pp_len;
 };
 
 // layout of the packed 128-bit rank key: fields in rank-rule order, most significant first

@@ -222,6 +222,8 @@ def load():
         "msb_add_facet_num": (None, [vp, ci, cd]),
         "msb_add_bool": (None, [vp, ci, ci]),
         "msb_end_doc": (None, [vp]),
+        "msb_add_raw_wordpos": (None, [vp, cu, ci, cu]),
+        "msb_add_raw_facet": (None, [vp, ci, cu]),
         "msb_finalize": (vp, [vp]),
         "mshard_free": (None, [vp]),
         "mshard_lookup_facet": (C.c_char_p, [vp, cu]),

@@ -24,7 +24,7 @@ typedef struct {
 typedef struct { hl_token_t *v; int n, cap; } hl_tokens_t;
 
 static void new_token(hl_tokens_t *ts, const m_chr_t *chars, int length, const char_se_t *se_all, int se_n) {
-    if (length == 0) return;
+    if (length <= 0) return;
     if (ts->n == ts->cap) { ts->cap = ts->cap ? ts->cap * 2 : 32; ts->v = realloc(ts->v, sizeof(hl_token_t) * (size_t)ts->cap); }
     hl_token_t *t = &ts->v[ts->n++];
     t->chars = malloc(sizeof(m_chr_t) * (size_t)length);
@@ -75,7 +75,9 @@ static void tokenize(const char *str, hl_tokens_t *ts) {
             if (whole) new_token(ts, token, len, se, se_n);
             is_hyphen = 0; is_abbrev = 0; len = 0; hs = 0;
         }
-        if (len >= 127) len = 0;
+        /* a token of 127 characters is dropped (highlight.c:141); unlike there, the hyphen state goes with it: a stale
+         * hyphen start past the new length made the next '-' ask for a token of negative length */
+        if (len >= 127) { len = 0; hs = 0; is_hyphen = 0; }
     }
     free(se);
 }

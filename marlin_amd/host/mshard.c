@@ -117,6 +117,7 @@ struct mshard_builder {
     m_u32map_t fstr_idx;       /* id -> index into fstr */
     uint32_t  *fstr_id; char **fstr; uint32_t nfstr, cap_fstr;
     uint64_t   total_wp;       /* sum of unique wids over docs */
+    uint32_t   raw_max_wid;    /* largest word id given through msb_add_raw_wordpos */
 };
 
 static void u32vec_push(u32vec_t *v, uint32_t x) {
@@ -176,6 +177,19 @@ void msb_add_word(mshard_builder_t *b, int i_priority, const m_chr_t *chars, int
         for (int i = 0; i < limit; i++) b->wid_tw[(size_t)wid * 3 + i] = tw[i];
     }
     push_widpos(b, wid, i_priority, (uint32_t)position);
+}
+
+/* One word occurrence by word id, past the dictionary (format tests: tests/test_docdata_format.py feeds the reference's
+ * own fixtures through here); the word gets a posting but no dictionary entry and no top-level ids */
+void msb_add_raw_wordpos(mshard_builder_t *b, uint32_t wid, int priority, uint32_t position) {
+    ensure_wid_cap(b, wid);
+    if (wid > b->raw_max_wid) b->raw_max_wid = wid;
+    push_widpos(b, wid, priority, position);
+}
+/* a facet id of the current document as it is, without a string behind it */
+static void add_facet_id(mshard_builder_t *b, int f_priority, uint32_t facet_id, const char *str);
+void msb_add_raw_facet(mshard_builder_t *b, int f_priority, uint32_t facet_id) {
+    add_facet_id(b, f_priority, facet_id, "");
 }
 
 struct an_data { mshard_builder_t *b; int priority; };
@@ -342,7 +356,7 @@ void msb_end_doc(mshard_builder_t *b) {
     b->dd_off[b->docid] = b->dd_n;
     b->dd_n += size + wlen;
     /* keep every blob 8-byte aligned so doubles can be read in place (LMDB values are) */
-    b->dd_n = (b->dd_n + 7) & ~(uint64_t)7;
+    { const uint64_t end = b->dd_n; b->dd_n = (b->dd_n + 7) & ~(uint64_t)7; memset(b->dd + end, 0, b->dd_n - end); }
     b->dd_off[b->docid + 1] = b->dd_n;
     b->in_doc = 0;
 }
@@ -377,6 +391,7 @@ mshard_t *msb_finalize(mshard_builder_t *b) {
     s->dd = b->dd; s->dd_off = b->dd_off;
     if (!s->dd) s->dd = calloc(8, 1);
     uint32_t W = mdict_word_count(b->dict), T = mdict_tword_count(b->dict);
+    if (b->raw_max_wid > W) { W = b->raw_max_wid; ensure_wid_cap(b, W); }
     s->word_count = W; s->tword_count = T;
 
     /* wid2bmap: count, then fill, walking the blobs in docid order */

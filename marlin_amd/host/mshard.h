@@ -94,6 +94,9 @@ void msb_add_facet_num(mshard_builder_t *b, int f_priority, double d);
 /* index_boolean (sindex.c:581-584) */
 void msb_add_bool(mshard_builder_t *b, int i_priority, int val);
 /* sindex_store_docdata (sindex.c:504-522) */
+/* format tests: an occurrence by word id (no dictionary entry), a facet id as it is */
+void msb_add_raw_wordpos(mshard_builder_t *b, uint32_t wid, int priority, uint32_t position);
+void msb_add_raw_facet(mshard_builder_t *b, int f_priority, uint32_t facet_id);
 void msb_end_doc(mshard_builder_t *b);
 /* builds every posting list; frees the builder */
 mshard_t *msb_finalize(mshard_builder_t *b);

@@ -54,9 +54,45 @@ _Static_assert(R_MAX + 1 <= M_MAX_RULES, "rank_rule length");
 /* ------------------------------------------------------------------ attached mirrors */
 #define SHIM_MAX_SHARDS 256
 #define SHIM_CTX_PER_DEVICE 16
-struct shim_entry { struct shard *shard; mshard_t *src; mmirror_t *mirror; int device; size_t txnid; };
+/* One generation of a shard's mirror.  Queries take a reference under the table's read lock (held for the lookup only,
+ * not for the GPU call) and drop it when their results are copied out; a refresh swaps the table entry under the write
+ * lock and retires the old generation, which is destroyed by whoever drops the last reference. */
+struct shim_mirror { mshard_t *src; mmirror_t *mirror; int device; size_t txnid; int refs, retired; };
+struct shim_entry { struct shard *shard; struct shim_mirror *m; };
 static struct shim_entry g_shards[SHIM_MAX_SHARDS];
+static int g_nshards;                                   /* entries in use are below this index */
 static pthread_rwlock_t g_shards_lock = PTHREAD_RWLOCK_INITIALIZER;
+static pthread_mutex_t g_ref_lock = PTHREAD_MUTEX_INITIALIZER;
+
+static void mirror_destroy(struct shim_mirror *m) {
+    if (!m) return;
+    mmirror_destroy(m->mirror);
+    mshard_free(m->src);
+    free(m);
+}
+static struct shim_mirror *mirror_acquire(const struct shard *s) {
+    struct shim_mirror *m = NULL;
+    pthread_rwlock_rdlock(&g_shards_lock);
+    for (int i = 0; i < g_nshards; i++) if (g_shards[i].shard == s) { m = g_shards[i].m; break; }
+    if (m) { pthread_mutex_lock(&g_ref_lock); m->refs++; pthread_mutex_unlock(&g_ref_lock); }
+    pthread_rwlock_unlock(&g_shards_lock);
+    return m;
+}
+static void mirror_release(struct shim_mirror *m) {
+    if (!m) return;
+    pthread_mutex_lock(&g_ref_lock);
+    const int last = --m->refs == 0 && m->retired;
+    pthread_mutex_unlock(&g_ref_lock);
+    if (last) mirror_destroy(m);
+}
+static void mirror_retire(struct shim_mirror *m) {        /* after the table no longer points to it */
+    if (!m) return;
+    pthread_mutex_lock(&g_ref_lock);
+    m->retired = 1;
+    const int idle = m->refs == 0;
+    pthread_mutex_unlock(&g_ref_lock);
+    if (idle) mirror_destroy(m);
+}
 /* execution contexts (one HIP stream + workspace each), handed out per call: execute_squery runs on search_pool
  * threads and on h2o threads alike (query.c:446,461) */
 static struct { mgpu_ctx_t *ctx[SHIM_CTX_PER_DEVICE]; int busy[SHIM_CTX_PER_DEVICE]; } g_ctx[64];
@@ -105,8 +141,10 @@ static int bridge_posting_dbi(mbridge_t *mb, MDB_txn *txn, MDB_dbi dbi, mbr_kind
     if (mdb_cursor_open(txn, dbi, &cur) != 0) return MGPU_E_ARG;
     MDB_val key, data;
     int rc = 0;
-    const uint8_t *cont[65536 / 64];            /* a docid space of 2^26 has at most 1024 containers */
-    uint32_t cont_len[65536 / 64];
+    /* a header names at most 65535 containers (u16 count): room for all of them */
+    const uint8_t **cont = malloc(sizeof(*cont) * 65536);
+    uint32_t *cont_len = malloc(sizeof(*cont_len) * 65536);
+    if (!cont || !cont_len) { free(cont); free(cont_len); mdb_cursor_close(cur); return MGPU_E_LIMIT; }
     for (MDB_cursor_op op = MDB_FIRST; !rc && mdb_cursor_get(cur, &key, &data, op) == 0; op = MDB_NEXT) {
         uint64_t k;
         if (key.mv_size != sizeof(k)) continue;
@@ -114,7 +152,7 @@ static int bridge_posting_dbi(mbridge_t *mb, MDB_txn *txn, MDB_dbi dbi, mbr_kind
         if (k & 0xFFFFu) continue;                                  /* a container value, fetched with its header */
         if (data.mv_size < 2) continue;
         uint16_t num_c; memcpy(&num_c, data.mv_data, 2);
-        if (num_c > sizeof(cont) / sizeof(cont[0]) || data.mv_size < 2u + 2u * num_c) { rc = MGPU_E_LIMIT; break; }
+        if (data.mv_size < 2u + 2u * num_c) { rc = MGPU_E_ARG; break; }
         for (uint32_t i = 0; i < num_c; i++) {
             uint16_t cid; memcpy(&cid, (const uint8_t *)data.mv_data + 2 + 2 * i, 2);
             uint64_t ck = k + cid + 1;
@@ -126,18 +164,21 @@ static int bridge_posting_dbi(mbridge_t *mb, MDB_txn *txn, MDB_dbi dbi, mbr_kind
         rc = mbr_add_posting(mb, kind, (uint32_t)(k >> 32), (uint32_t)((k >> 16) & 0xFFFFu), &stored);
     }
     mdb_cursor_close(cur);
+    free(cont); free(cont_len);
     return rc;
 }
 
 void mgpu_shim_detach_shard(struct shard *s) {
+    struct shim_mirror *old = NULL;
     pthread_rwlock_wrlock(&g_shards_lock);
-    for (int i = 0; i < SHIM_MAX_SHARDS; i++) {
+    for (int i = 0; i < g_nshards; i++) {
         if (g_shards[i].shard != s) continue;
-        mmirror_destroy(g_shards[i].mirror);
-        mshard_free(g_shards[i].src);
+        old = g_shards[i].m;
         memset(&g_shards[i], 0, sizeof(g_shards[i]));
+        break;
     }
     pthread_rwlock_unlock(&g_shards_lock);
+    mirror_retire(old);                                    /* queries that hold it finish on it */
 }
 
 /* Every word of the shard's dtrie as a flat list (the input of mgpu_dict_create): a depth-first walk over the mapped
@@ -146,7 +187,8 @@ void mgpu_shim_detach_shard(struct shard *s) {
 struct dict_out { uint32_t *chars, *off, *wid; uint32_t n, nchars, ccap, wcap; chr_t *path; uint32_t pcap; int oom; };
 static void dict_walk(struct dtrie *dt, const struct dnode *n, uint32_t depth, struct dict_out *o) {
     if (o->oom) return;
-    if (n->has_wid && depth) {
+    /* a node whose word id is 0 holds no word: every get_wid user skips it (dtrie.c:648-651, 742-746) */
+    if (n->has_wid && depth && *(const uint32_t *)((const uint8_t *)n + sizeof(struct dnode) + n->num_child * sizeof(struct dnode_ptr))) {
         const uint32_t *widpos = (const uint32_t *)((const uint8_t *)n + sizeof(struct dnode) + n->num_child * sizeof(struct dnode_ptr));
         if (o->n + 1 >= o->wcap) {
             o->wcap = o->wcap ? o->wcap * 2 : 4096;
@@ -191,8 +233,10 @@ int mgpu_shim_attach_shard(struct shard *s, int device) {
     MDB_txn *txn;
     if (mdb_txn_begin(si->env, NULL, MDB_RDONLY, &txn) != 0) return MGPU_E_ARG;
     const size_t snap_txnid = mdb_txn_id(txn);                      /* the commit this snapshot reflects */
-    mbridge_t *mb = mbr_new(map->num_numbers, map->num_bools, map->num_facets,
-                            si->trie->meta->word_count, si->trie->meta->tword_count);
+    pthread_rwlock_rdlock(&si->trie->trie_lock);               /* the writer bumps the counts under the write lock */
+    const uint32_t word_count = si->trie->meta->word_count, tword_count = si->trie->meta->tword_count;
+    pthread_rwlock_unlock(&si->trie->trie_lock);
+    mbridge_t *mb = mbr_new(map->num_numbers, map->num_bools, map->num_facets, word_count, tword_count);
     int rc = mb ? 0 : MGPU_E_LIMIT;
     if (!rc) rc = bridge_posting_dbi(mb, txn, si->wid2bmap_dbi, MBR_WID);
     if (!rc) rc = bridge_posting_dbi(mb, txn, si->twid2bmap_dbi, MBR_TWID);
@@ -243,18 +287,25 @@ int mgpu_shim_attach_shard(struct shard *s, int device) {
         mmirror_destroy(mirror); mshard_free(src);
         return rc;
     }
-    mgpu_shim_detach_shard(s);
+    struct shim_mirror *nm = calloc(1, sizeof(*nm));
+    if (!nm) { mmirror_destroy(mirror); mshard_free(src); return MGPU_E_LIMIT; }
+    nm->src = src; nm->mirror = mirror; nm->device = device; nm->txnid = snap_txnid;
+    /* ONE write-locked section replaces the entry (or takes a free slot): a query either finds the old generation or
+     * the new one, never none; the old one is retired after the lock is dropped and dies with its last query */
+    struct shim_mirror *old = NULL;
+    int at = -1;
     pthread_rwlock_wrlock(&g_shards_lock);
-    rc = MGPU_E_LIMIT;
-    for (int i = 0; i < SHIM_MAX_SHARDS; i++) {
-        if (g_shards[i].shard) continue;
-        g_shards[i] = (struct shim_entry){ s, src, mirror, device, snap_txnid };
-        rc = 0;
-        break;
+    for (int i = 0; i < g_nshards; i++) if (g_shards[i].shard == s) { at = i; break; }
+    if (at < 0) for (int i = 0; i < SHIM_MAX_SHARDS; i++) if (!g_shards[i].shard) { at = i; break; }
+    if (at >= 0) {
+        old = g_shards[at].shard == s ? g_shards[at].m : NULL;
+        g_shards[at].shard = s; g_shards[at].m = nm;
+        if (at >= g_nshards) g_nshards = at + 1;
     }
     pthread_rwlock_unlock(&g_shards_lock);
-    if (rc) { mmirror_destroy(mirror); mshard_free(src); }
-    return rc;
+    if (at < 0) { mirror_destroy(nm); return MGPU_E_LIMIT; }     /* table full: the shard keeps the mirror it had */
+    mirror_retire(old);
+    return 0;
 }
 
 /* ------------------------------------------------------------------ struct query -> m_query_t */
@@ -360,17 +411,15 @@ void execute_squery(void *w) {
     if (q->agg) res->agg = aggs_dup(q->agg);
 
     /* the shard's mirror */
-    mmirror_t *mirror = NULL; int device = 0;
-    pthread_rwlock_rdlock(&g_shards_lock);
-    for (int i = 0; i < SHIM_MAX_SHARDS; i++) if (g_shards[i].shard == sq->shard) { mirror = g_shards[i].mirror; device = g_shards[i].device; break; }
-    if (!mirror) {
-        pthread_rwlock_unlock(&g_shards_lock);
+    struct shim_mirror *gen = mirror_acquire(sq->shard);
+    if (!gen) {
         M_ERR("gpu squery: shard %d has no mirror (mgpu_shim_attach_shard was not called)", sq->shard_idx);
         finish(sq);
         return;
     }
+    mmirror_t *mirror = gen->mirror; const int device = gen->device;
     if (num_terms > M_MAX_QTERMS || q->num_words > M_MAX_QWORDS) {
-        pthread_rwlock_unlock(&g_shards_lock);
+        mirror_release(gen);
         M_ERR("gpu squery: query has %d words, limit %d", q->num_words, M_MAX_QWORDS);
         finish(sq);
         return;
@@ -428,7 +477,6 @@ void execute_squery(void *w) {
     memset(&out, 0, sizeof(out));
     if (!rc) rc = msq_execute_plan(ctx, mirror, mq, &plan, sq->shard_idx, &out);
     if (ctx) ctx_release(device, slot);
-    pthread_rwlock_unlock(&g_shards_lock);
 
     if (rc) {
         M_ERR("gpu squery: shard %d: error %d %s", sq->shard_idx, rc, mgpu_last_error());
@@ -450,20 +498,21 @@ void execute_squery(void *w) {
     m_sqresult_free(&out);
     mplan_free(&plan);
     mq_free(mq);
+    mirror_release(gen);
     finish(sq);
 }
 
 /* Row f-2, the part that exists: refresh keyed on the commit.  Call where a bulk write ends (sindex.c:246).  When the
  * environment's last committed transaction is newer than the one the mirror was built from, a new mirror is built from
  * a fresh read snapshot NEXT to the live one -- queries keep running on the old mirror -- and swapped in under the
- * table's write lock (mgpu_shim_attach_shard); otherwise nothing happens.  The rebuild is complete, not incremental.
+ * table's write lock (mgpu_shim_attach_shard: one locked section, the old generation dies with its last query);
+ * otherwise nothing happens.  The rebuild is complete, not incremental.
  * Returns 0 (up to date or refreshed), 1 when the shard was never attached, or an MGPU_E_* code. */
 int mgpu_shim_refresh_shard(struct shard *s) {
-    int device = -1; size_t have = 0;
-    pthread_rwlock_rdlock(&g_shards_lock);
-    for (int i = 0; i < SHIM_MAX_SHARDS; i++) if (g_shards[i].shard == s) { device = g_shards[i].device; have = g_shards[i].txnid; break; }
-    pthread_rwlock_unlock(&g_shards_lock);
-    if (device < 0) return 1;
+    struct shim_mirror *gen = mirror_acquire(s);
+    if (!gen) return 1;
+    const int device = gen->device; const size_t have = gen->txnid;
+    mirror_release(gen);
     MDB_envinfo info;
     if (mdb_env_info(s->sindex->env, &info) != 0) return MGPU_E_ARG;
     if (info.me_last_txnid <= have) return 0;

@@ -28,7 +28,9 @@ int main(void) {
         m_query_t *q = mq_new(0);
         if (mq_set_text(q, qtext) != 0) { mq_free(q); continue; }
         for (int i = 0; i < 8; i++) {
-            gen_text(text, 399, alpha);
+            /* every fourth text is letters and hyphens only: tokens that reach the tokenizer's 127-character limit with
+             * a hyphen open (the case that asked for a token of negative length) */
+            gen_text(text, 399, (i & 3) == 3 ? ((round & 1) ? "ab" : "aaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaa-") : alpha);
             char *h = m_highlight(text, q, (i & 1) ? 0 : (int)(rnd() % 5));
             strings++;
             if (h) {
@@ -36,6 +38,21 @@ int main(void) {
                 if (strlen(h) > strlen(text) + 13 * 400) { printf("highlight grew beyond its bound\n"); return 2; }
                 m_highlight_free(h);
             }
+        }
+        mq_free(q);
+    }
+    {   /* the constructed case: "ab-" + 126 letters + "-" + more letters */
+        char text[400]; int n = 0;
+        memcpy(text, "ab-", 3); n = 3;
+        for (int i = 0; i < 126; i++) text[n++] = 'c';
+        text[n++] = '-';
+        for (int i = 0; i < 130; i++) text[n++] = 'd';
+        memcpy(text + n, " ab", 4);
+        m_query_t *q = mq_new(0);
+        if (mq_set_text(q, "ab") == 0) {
+            char *h = m_highlight(text, q, 0);
+            if (!h || !strstr(h, "<mark>ab</mark>")) { printf("long hyphenated token: %s\n", h ? h : "(null)"); return 3; }
+            m_highlight_free(h);
         }
         mq_free(q);
     }
