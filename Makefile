@@ -62,6 +62,31 @@ oracle/_ref/ref_seam: oracle/ref_seam.c
 	$(CC) -std=gnu99 -O1 -g -w -D_GNU_SOURCE -DH2O_USE_LIBUV=0 $(REF_INC) oracle/ref_seam.c \
 	    $(REF)/deps/lmdb/mdb.c $(REF)/deps/lmdb/midl.c $(REF)/src/utils/mlog.c -Wl,--unresolved-symbols=ignore-all -o $@ -lpthread -lm
 
+# The reference's own shard query path on a shard its own indexing code built (oracle/ref_query.c): sindex.c, aggs.c and
+# metric-aggs.c are compiled by inclusion, everything else of the reference as it lies.  No -DNDEBUG: farmhash32 then applies its
+# debug tweak (farmhash-c.c:287-293), the variant m_facet_id restates.  Build container only.
+REF_M = $(REF)/src/main
+REF_QSRC = $(REF_M)/docrank.c $(REF_M)/filter_apply.c $(REF_M)/filter.c $(REF_M)/sort.c $(REF_M)/hashtable.c \
+           $(REF_M)/bmap.c $(REF_M)/cont.c $(REF_M)/mbmap.c $(REF_M)/dtrie.c $(REF_M)/query.c $(REF_M)/highlight.c $(REF_M)/shard.c \
+           $(REF_M)/sdata.c $(REF_M)/mapping.c $(REF_M)/workers.c $(REF_M)/debug.c $(REF)/src/utils/utils.c \
+           $(REF)/src/utils/farmhash-c.c $(REF)/src/utils/mlog.c $(REF)/src/utils/threadpool.c $(REF)/src/utils/lz4.c \
+           $(REF)/src/analyzer/analyzer.c $(REF)/src/analyzer/default_analyzer.c $(REF)/src/analyzer/whitespace_analyzer.c \
+           $(REF)/src/analyzer/word.c $(REF)/deps/utf8proc/utf8proc.c $(REF)/deps/lmdb/mdb.c $(REF)/deps/lmdb/midl.c
+REF_QFLAGS = -std=gnu99 -O2 -g -w -D_GNU_SOURCE -DH2O_USE_LIBUV=0 -DH20_USE_EPOLL $(REF_INC)
+ref-query: oracle/_ref/ref_query
+oracle/_ref/ref_query: oracle/ref_query.c
+	@mkdir -p oracle/_ref
+	$(CC) $(REF_QFLAGS) oracle/ref_query.c $(REF_M)/squery.c $(REF_QSRC) -Wl,--unresolved-symbols=ignore-all -o $@ -lpthread -lm -lz
+
+# The same program with shim/squery_gpu.c IN PLACE OF the reference's squery.c: the reference's indexing, dtrie, LMDB and
+# query structures on the host, the shard query itself on the GPU through the seam.  Runs on the GPU box (oracle/_ref/
+# travels); tests/test_gpu_shim_seam.py compares it with ref_query.
+ref-query-gpu: oracle/_ref/ref_query_gpu
+oracle/_ref/ref_query_gpu: oracle/ref_query.c shim/_build/squery_gpu.o marlin_amd/lib/libmarlin_host.so
+	@mkdir -p oracle/_ref
+	$(CC) $(REF_QFLAGS) -DREF_QUERY_GPU oracle/ref_query.c shim/_build/squery_gpu.o $(REF_QSRC) -Wl,--unresolved-symbols=ignore-all \
+	    -Lmarlin_amd/lib -lmarlin_host -lmarlin_gpu -Wl,-rpath,'$$ORIGIN/../../marlin_amd/lib' -o $@ -lpthread -lm -lz
+
 # The drop-in replacement for the reference's squery.c, compiled against the reference's own headers (same include
 # paths as `ref`).  Build container only; the object never travels and nothing links it here: the check is that it
 # compiles without warnings and exports execute_squery / sqresult_free (tests/test_shim.py).
@@ -76,4 +101,4 @@ shim/_build/squery_gpu.o: shim/squery_gpu.c $(HOST_HDR)
 clean:
 	rm -f marlin_amd/lib/*.so oracle/liborc.so oracle/_ref/*.so shim/_build/*.o
 
-.PHONY: all gpu gpu-checked host oracle ref ref-seam shim clean
+.PHONY: all gpu gpu-checked host oracle ref ref-seam ref-query ref-query-gpu shim clean

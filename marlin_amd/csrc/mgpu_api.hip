@@ -429,7 +429,10 @@ static int shard_create_impl(int device, const mgpu_shard_desc_t *d, mgpu_shard_
             }
             if ((rc = upload(s, rec, &sd.rec))) { mgpu_shard_destroy(s); return rc; }
             { const uint8_t *pl; if ((rc = upload(s, rlen, &pl))) { mgpu_shard_destroy(s); return rc; } sd.rec_len = pl; }
-            s->rec_len_ok = N <= (1u << 24) && !getenv("MGPU_NO_RECLEN");
+            // Off unless MGPU_RECLEN is set: measured on the bench corpus the predicated loads change nothing (0.660 vs
+            // 0.655 ms per batch: the kernel is bound by instruction issue and latency, not by bytes) while the length
+            // gather adds a third of a fabric request per hit to the counters (profiles/README.md, round 3)
+            s->rec_len_ok = N <= (1u << 24) && getenv("MGPU_RECLEN") != nullptr;
             sd.rec_ws = ws_c; sd.rec_words = (uint32_t)rec.size();
             if (all_staged)
                 for (int f = 0; f < d->num_facets; f++) {

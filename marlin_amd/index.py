@@ -203,6 +203,8 @@ class ParsedQuery:
         self.jq = jq
         self.q = lib.mq_new(len(index.facets))
         self.explain = bool(jq.get("explain", False))
+        self.filter_strs = {}
+        self.agg_names = []
         q = self.q.contents
         try:
             merged = dict(index.settings)
@@ -314,6 +316,7 @@ class ParsedQuery:
             c.field_type = ffi.MT_STRING
             b = v.encode()
             c.facet_id = self.index.lib.m_facet_id(b, len(b))
+            self.filter_strs[C.addressof(c)] = v          # filter.strval, for callers that want the string itself
         elif isinstance(v, bool):
             c.field_type = ffi.MT_BOOLEAN; c.numval = 1.0 if v else 0.0
         elif isinstance(v, (int, float)):

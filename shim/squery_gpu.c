@@ -150,6 +150,13 @@ static int bridge_posting_dbi(mbridge_t *mb, MDB_txn *txn, MDB_dbi dbi, mbr_kind
         if (key.mv_size != sizeof(k)) continue;
         memcpy(&k, key.mv_data, sizeof(k));
         if (k & 0xFFFFu) continue;                                  /* a container value, fetched with its header */
+        const uint32_t id = (uint32_t)(k >> 32), prio = (uint32_t)((k >> 16) & 0xFFFFu);
+        /* Word, top-level-word and twid->wid sets are stored once for all fields (priority 0) and once per field
+         * (priority = field + 1: string_new_word_pos, sindex.c:676-699); the query path reads the priority-0 ones only
+         * (squery.c:39-46).  The boolean database also holds the dtrie's free-node maps under id 0xFFFFFFFF in another
+         * format (dtrie.c:490-527): not postings. */
+        if ((kind == MBR_WID || kind == MBR_TWID || kind == MBR_TWID_WIDS) && prio != 0) continue;
+        if (kind == MBR_BOOL && id > 1) continue;
         if (data.mv_size < 2) continue;
         uint16_t num_c; memcpy(&num_c, data.mv_data, 2);
         if (data.mv_size < 2u + 2u * num_c) { rc = MGPU_E_ARG; break; }
@@ -161,7 +168,7 @@ static int bridge_posting_dbi(mbridge_t *mb, MDB_txn *txn, MDB_dbi dbi, mbr_kind
             else { cont[i] = NULL; cont_len[i] = 0; }              /* mbmap_load_bmap logs and carries on (mbmap.c:276-278) */
         }
         mgpu_mbmap_t stored = { data.mv_data, (uint32_t)data.mv_size, cont, cont_len };
-        rc = mbr_add_posting(mb, kind, (uint32_t)(k >> 32), (uint32_t)((k >> 16) & 0xFFFFu), &stored);
+        rc = mbr_add_posting(mb, kind, id, prio, &stored);
     }
     mdb_cursor_close(cur);
     free(cont); free(cont_len);
