@@ -90,7 +90,10 @@ oracle/_ref/ref_query_gpu: oracle/ref_query.c shim/_build/squery_gpu.o marlin_am
 # The drop-in replacement for the reference's squery.c, compiled against the reference's own headers (same include
 # paths as `ref`).  Build container only; the object never travels and nothing links it here: the check is that it
 # compiles without warnings and exports execute_squery / sqresult_free (tests/test_shim.py).
-shim: shim/_build/squery_gpu.o
+shim: shim/_build/squery_gpu.o shim/_build/query_gpu.o
+shim/_build/query_gpu.o: shim/query_gpu.c
+	@mkdir -p shim/_build
+	$(CC) -std=gnu99 -O2 -fPIC -w -D_GNU_SOURCE -DH2O_USE_LIBUV=0 $(REF_INC) -c shim/query_gpu.c -o $@
 shim/_build/squery_gpu.o: shim/squery_gpu.c $(HOST_HDR)
 	@mkdir -p shim/_build
 	$(CC) -std=gnu99 -O2 -fPIC -Wall -Wextra -Wno-unused-parameter -Wno-sign-compare -Werror -D_GNU_SOURCE -DH2O_USE_LIBUV=0 \

@@ -776,6 +776,26 @@ int msq_execute_plan(mgpu_ctx_t *ctx, const mmirror_t *m, const m_query_t *q, co
     return rc;
 }
 
+/* the same for n pairs in ONE batch of launches: every shard of a query, or of several queries (a replacement
+ * execute_query, shim/query_gpu.c); all mirrors on the context's device.  outs[i] is filled on success only. */
+int msq_execute_plans(mgpu_ctx_t *ctx, const mmirror_t *const *ms, const m_query_t *const *qs, const mplan_t *const *pls,
+                      const int *shard_idx, int n, m_sqresult_t *outs) {
+    if (!ctx || n <= 0) return MGPU_E_ARG;
+    mgpu_sqout_t *g = calloc((size_t)n, sizeof(*g));
+    mgpu_shard_t **gs = malloc(sizeof(*gs) * (size_t)n);
+    mgpu_plan_t *gp = malloc(sizeof(*gp) * (size_t)n);
+    if (!g || !gs || !gp) { free(g); free(gs); free(gp); return MGPU_E_LIMIT; }
+    for (int i = 0; i < n; i++) { gs[i] = ms[i]->g; gp[i] = pls[i]->p; memset(&outs[i], 0, sizeof(outs[i])); }
+    int rc = mgpu_execute(ctx, gs, gp, n, g);
+    for (int i = 0; i < n && !rc; i++) {
+        rc = sqout_to_result(qs[i], shard_idx[i], ms[i]->s->num_facets, &g[i], &outs[i]);
+        if (rc) for (int k = 0; k <= i; k++) m_sqresult_free(&outs[k]);
+    }
+    for (int i = 0; i < n; i++) mgpu_sqout_free(&g[i]);
+    free(g); free(gs); free(gp);
+    return rc;
+}
+
 int msq_execute_prepared(mgpu_ctx_t *ctx, const msq_prepared_t *pp, m_sqresult_t *outs) {
     int rc = msq_submit_prepared(ctx, pp);
     if (rc) { memset(outs, 0, sizeof(*outs) * (size_t)pp->n); return rc; }

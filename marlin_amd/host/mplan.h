@@ -73,6 +73,8 @@ int  msq_execute_batch(mgpu_ctx_t *ctx, mmirror_t *const *mirrors, int num_shard
 typedef struct msq_prepared msq_prepared_t;
 int  msq_prepare_batch(mmirror_t *const *mirrors, int num_shards, const m_query_t *const *queries,
                        int nq, int capture, msq_prepared_t **out);
+int  msq_execute_plans(mgpu_ctx_t *ctx, const mmirror_t *const *ms, const m_query_t *const *qs, const mplan_t *const *pls,
+                       const int *shard_idx, int n, m_sqresult_t *outs);
 int  msq_execute_prepared(mgpu_ctx_t *ctx, const msq_prepared_t *pp, m_sqresult_t *outs);
 /* execute_prepared in two halves (one batch in flight per context): submit enqueues the GPU work and returns,
  * collect waits for it and decodes; pp must stay alive in between */

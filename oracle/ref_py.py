@@ -30,11 +30,14 @@ def _hx(s):
     return s.encode("utf-8").hex() or "00"[:0]
 
 
-def index_commands(ix, workdir):
-    out = ["I %s %d %d %d %d %d" % (workdir, ix.num_shards, len(ix.strings), len(ix.numbers), len(ix.bools), len(ix.facets))]
+def index_commands(ix, workdir, skip=None):
+    """skip: documents per shard that are already indexed (a second bulk write appends the rest)"""
+    out = [] if skip else ["I %s %d %d %d %d %d" % (workdir, ix.num_shards, len(ix.strings), len(ix.numbers), len(ix.bools), len(ix.facets))]
     for s in range(ix.num_shards):
         out.append("W %d" % s)
         for docid, d in enumerate(ix.docs[s], 1):
+            if skip and docid <= skip[s]:
+                continue
             out.append("D %d" % docid)
             for k, v in d.items():                           # parse_index_document, sindex.c:792-893
                 f = ix.fields.get(k)
@@ -132,3 +135,31 @@ def run(ix, pqs, gpu=False, env=None, timeout=600):
     if p.returncode != 0:
         raise RuntimeError("ref_query exited with %d\n%s\n%s" % (p.returncode, p.stdout[-2000:], p.stderr[-4000:]))
     return parse_output(p.stdout, ix.num_shards, len(pqs))
+
+
+def run_two_writes(ix_a, ix_ab, pqs_a, pqs_ab, gpu=False, timeout=600):
+    """a second bulk write after the first queries: ix_ab holds ix_a's documents and more, in the same shards and order.
+    gpu: the mirror is attached after the first write and REFRESHED (mgpu_shim_refresh_shard) after the second.
+    Returns (results of pqs_a on the first state, results of pqs_ab on the second)."""
+    for s in range(ix_a.num_shards):
+        assert ix_ab.docs[s][:len(ix_a.docs[s])] == ix_a.docs[s]
+    with tempfile.TemporaryDirectory() as tmp:
+        cmds = index_commands(ix_a, os.path.join(tmp, "ix"))
+        if gpu:
+            cmds.append("X")
+        for pq in pqs_a:
+            cmds += query_commands(ix_a, pq)
+        cmds += index_commands(ix_ab, None, skip=[len(d) for d in ix_a.docs])
+        if gpu:
+            cmds.append("Y")
+        for pq in pqs_ab:
+            cmds += query_commands(ix_ab, pq)
+        p = subprocess.run([EXE_GPU if gpu else EXE], input="\n".join(cmds) + "\n", text=True, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, timeout=timeout)
+    if p.returncode != 0:
+        raise RuntimeError("ref_query exited with %d\n%s\n%s" % (p.returncode, p.stdout[-2000:], p.stderr[-4000:]))
+    allres = parse_output(p.stdout, ix_a.num_shards, len(pqs_a) + len(pqs_ab))
+    refreshed = [ln.split() for ln in p.stdout.splitlines() if ln.startswith("refresh ")]
+    if gpu:
+        assert len(refreshed) == ix_a.num_shards and all(t[2] == "0" for t in refreshed), refreshed
+    return allres[:len(pqs_a)], allres[len(pqs_a):]

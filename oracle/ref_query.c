@@ -26,6 +26,7 @@
  *   A <type> <field>                 aggregation
  *   R                                execute_squery on every shard, print, sqresult_free
  *   X                                (ref_query_gpu) mgpu_shim_attach_shard for every shard
+ *   Y                                (ref_query_gpu) mgpu_shim_refresh_shard for every shard (after further W .. C blocks)
  * stdout per shard of a run:
  *   shard <i> hits <n> rank_count <n> fast <0|1>
  *   rank <docid> <typos> <proximity> <field> <position> <exact> <compare bits>      rank_count lines, in result order
@@ -42,6 +43,8 @@
 
 #ifdef REF_QUERY_GPU
 int mgpu_shim_attach_shard(struct shard *s, int device);
+void mgpu_shim_execute_squeries(struct squery *sq, int n);
+int mgpu_shim_refresh_shard(struct shard *s);
 #endif
 
 static struct app g_app;
@@ -150,6 +153,9 @@ int main(void) {
 #ifdef REF_QUERY_GPU
         case 'X': for (int i = 0; i < g_in.num_shards; i++) { int rc = mgpu_shim_attach_shard(g_shard[i], 0); if (rc) { printf("attach %d failed %d\n", i, rc); fflush(stdout); return 5; } } printf("attached\n"); break;
 #endif
+#ifdef REF_QUERY_GPU
+        case 'Y': for (int i = 0; i < g_in.num_shards; i++) { int rc = mgpu_shim_refresh_shard(g_shard[i]); printf("refresh %d %d\n", i, rc); } break;
+#endif
         case 'Q':
             q = query_new(&g_in);
             q->page_num = 1;
@@ -212,11 +218,18 @@ int main(void) {
             } else q->rank_rule[q->cfg.num_rules] = R_DONE;
             memcpy(&q->rank_rule[rcount], q->cfg.rank_algo, q->cfg.num_rules * sizeof(SORT_RULE));
             generate_query_terms(q);
+            struct squery sqs[64];
+            memset(sqs, 0, sizeof(sqs));
+            for (int i = 0; i < g_in.num_shards; i++) { sqs[i].q = q; sqs[i].shard_idx = i; sqs[i].shard = g_shard[i]; }
+#ifdef REF_QUERY_GPU
+            /* several shards: the entry a replacement execute_query uses, every shard of the query in one GPU batch */
+            if (g_in.num_shards > 1) mgpu_shim_execute_squeries(sqs, g_in.num_shards);
+            else execute_squery(&sqs[0]);
+#else
+            for (int i = 0; i < g_in.num_shards; i++) execute_squery(&sqs[i]);
+#endif
             for (int i = 0; i < g_in.num_shards; i++) {
-                struct squery sq;
-                memset(&sq, 0, sizeof(sq));
-                sq.q = q; sq.shard_idx = i; sq.shard = g_shard[i];
-                execute_squery(&sq);
+                struct squery sq = sqs[i];
                 struct squery_result *r = sq.sqres;
                 printf("shard %d hits %d rank_count %d fast %d\n", i, r->num_hits, r->rank_count, sq.fast_rank ? 1 : 0);
                 for (int j = 0; j < r->rank_count; j++) {

@@ -6,6 +6,7 @@
  *      void sqresult_free(struct query *q, struct squery_result *sqres);
  * with the reference's calling convention (query.c:446 threadpool job, query.c:461 inline call, query.c:468-470
  * free), and two set-up calls a maintainer adds where a shard is opened / after a bulk commit (sindex.c:246):
+ *      void mgpu_shim_execute_squeries(struct squery *sq, int n);  -- n (query, shard) pairs as one GPU batch (query_gpu.c)
  *      int  mgpu_shim_attach_shard(struct shard *s, int device);   -- mirror the shard's LMDB into HBM
  *      int  mgpu_shim_refresh_shard(struct shard *s);              -- after a commit: rebuild + swap if LMDB moved on
  *      void mgpu_shim_detach_shard(struct shard *s);
@@ -400,14 +401,30 @@ static void finish(struct squery *sq) {
     if (sq->worker) worker_done(sq->worker);
 }
 
-void execute_squery(void *w) {
-    struct squery *sq = w;
-    struct query *q = sq->q;
-    const int num_terms = (int)kv_size(q->terms);
-    const int num_facets = q->in->mapping->num_facets;
-    khiter_t k;
+/* One (query, shard) pair on its way through the seam.  execute_squery is a batch of one; a replacement execute_query
+ * (shim/query_gpu.c) hands over every shard of a query -- or of all the queries of a "requests" array -- at once, and
+ * they go to the device as ONE batch of launches per GPU. */
+struct sq_job {
+    struct squery *sq;
+    struct shim_mirror *gen;
+    m_query_t *mq;
+    m_termresult_t tr[M_MAX_QTERMS];
+    uint32_t exact_wid[M_MAX_QWORDS];
+    int num_terms, first_lookup, num_lookups, lookup_term[M_MAX_QTERMS];
+    mplan_t plan;
+    m_sqresult_t out;
+    int rc, planned;
+};
 
-    /* what form_result and sqresult_free expect to find, whatever happens below (squery.c:20-37) */
+/* squery_result_new + init_facet_hash + aggs_dup (squery.c:20-37, 494-498), the mirror, and the host half of
+ * lookup_terms (squery.c:144-167): short prefixes and terms without typos are exact descents of the dtrie
+ * (dtrie.c:805-823) and run here; the typo walks are collected for the device */
+static void job_begin(struct sq_job *j, struct squery *sq, mgpu_term_lookup_t **lk, int *nlk, int *caplk) {
+    struct query *q = sq->q;
+    const int num_facets = q->in->mapping->num_facets;
+    memset(j, 0, sizeof(*j));
+    j->sq = sq;
+    j->num_terms = (int)kv_size(q->terms);
     struct squery_result *res = calloc(1, sizeof(*res));
     sq->sqres = res;
     sq->fast_rank = false;
@@ -417,96 +434,155 @@ void execute_squery(void *w) {
     res->fc = calloc(num_facets ? num_facets : 1, sizeof(struct facet_count *));
     if (q->agg) res->agg = aggs_dup(q->agg);
 
-    /* the shard's mirror */
-    struct shim_mirror *gen = mirror_acquire(sq->shard);
-    if (!gen) {
+    j->gen = mirror_acquire(sq->shard);
+    if (!j->gen) {
         M_ERR("gpu squery: shard %d has no mirror (mgpu_shim_attach_shard was not called)", sq->shard_idx);
-        finish(sq);
+        j->rc = MGPU_E_ARG;
         return;
     }
-    mmirror_t *mirror = gen->mirror; const int device = gen->device;
-    if (num_terms > M_MAX_QTERMS || q->num_words > M_MAX_QWORDS) {
-        mirror_release(gen);
+    if (j->num_terms > M_MAX_QTERMS || q->num_words > M_MAX_QWORDS) {
         M_ERR("gpu squery: query has %d words, limit %d", q->num_words, M_MAX_QWORDS);
-        finish(sq);
+        j->rc = MGPU_E_LIMIT;
         return;
     }
-
-    /* lookup_terms (squery.c:144-167).  dtrie_lookup_term's three modes (dtrie.c:805-823): short prefixes and terms
-     * without typos are exact descents and stay with the dtrie; the typo walk goes to the device, all terms in one call */
     struct sindex *si = sq->shard->sindex;
-    m_termresult_t tr[M_MAX_QTERMS];
-    uint32_t exact_wid[M_MAX_QWORDS];
-    mgpu_term_lookup_t lk[M_MAX_QTERMS]; int lk_term[M_MAX_QTERMS]; int nlk = 0;
-    for (int t = 0; t < num_terms; t++) {
+    mmirror_t *mirror = j->gen->mirror;
+    j->first_lookup = *nlk;
+    for (int t = 0; t < j->num_terms; t++) {
         term_t *tm = kv_A(q->terms, t);
-        tr[t].twid = 0;
-        m_u32map_init(&tr[t].wordids);
+        j->tr[t].twid = 0;
+        m_u32map_init(&j->tr[t].wordids);
         const int walk = tm->typos && !(tm->prefix && tm->word->length <= LEVLIMIT) && mirror->gd &&
                          tm->word->length >= 1 && tm->word->length <= MGPU_MAX_TERM_LEN;
         if (walk) {
-            lk[nlk].dict = mirror->gd; lk[nlk].chars = (const uint32_t *)tm->word->chars; lk[nlk].len = tm->word->length; lk[nlk].prefix = tm->prefix;
-            lk_term[nlk++] = t;
+            if (*nlk == *caplk) {
+                *caplk = *caplk ? *caplk * 2 : 64;
+                *lk = realloc(*lk, sizeof(**lk) * (size_t)*caplk);
+            }
+            mgpu_term_lookup_t *l = &(*lk)[(*nlk)++];
+            l->dict = mirror->gd; l->chars = (const uint32_t *)tm->word->chars; l->len = tm->word->length; l->prefix = tm->prefix;
+            j->lookup_term[j->num_lookups++] = t;
             continue;
         }
         termresult_t *r = dtrie_lookup_term(si->trie, tm);
-        tr[t].twid = r->twid;
+        j->tr[t].twid = r->twid;
         uint32_t wid; int dist;
-        kh_foreach(r->wordids, wid, dist, { m_u32map_set(&tr[t].wordids, wid, dist); });
+        kh_foreach(r->wordids, wid, dist, { m_u32map_set(&j->tr[t].wordids, wid, dist); });
         termresult_free(r);
     }
-    for (int i = 0; i < q->num_words; i++) exact_wid[i] = dtrie_lookup_exact(si->trie, kv_A(q->words, i));
-    int rc = 0;
-    int slot = 0;
-    mgpu_ctx_t *ctx = ctx_acquire(device, &slot);
-    if (!ctx) rc = MGPU_E_HIP;
-    if (!rc && nlk) {
-        mgpu_term_hit_t *hits = NULL; uint32_t nh = 0;
-        rc = mgpu_lookup_terms(ctx, lk, nlk, &hits, &nh);
-        for (uint32_t h = 0; !rc && h < nh; h++) {
-            if (hits[h].lookup >= (uint32_t)nlk) { rc = MGPU_E_HIP; break; }
-            m_u32map_t *m = &tr[lk_term[hits[h].lookup]].wordids;
-            if ((int)hits[h].dist < m_u32map_get(m, hits[h].wid, 0xFF)) m_u32map_set(m, hits[h].wid, (int32_t)hits[h].dist);
-        }
-        mgpu_term_hits_free(hits);
-    }
+    for (int i = 0; i < q->num_words; i++) j->exact_wid[i] = dtrie_lookup_exact(si->trie, kv_A(q->words, i));
+}
 
-    /* struct query -> plan */
-    m_query_t *mq = lower_query(q, num_facets);
-    if (!rc) rc = lower_aggs(q->agg, mq);
-    mplan_t plan;
-    memset(&plan, 0, sizeof(plan));
-    if (!rc) rc = mplan_from_terms(mirror, mq, tr, exact_wid, 0, &plan);
-    for (int t = 0; t < num_terms; t++) m_termresult_free(&tr[t]);
+/* struct query -> plan, once the device's term hits are in */
+static void job_plan(struct sq_job *j) {
+    struct query *q = j->sq->q;
+    j->mq = lower_query(q, q->in->mapping->num_facets);
+    if (!j->rc) j->rc = lower_aggs(q->agg, j->mq);
+    if (!j->rc) { j->rc = mplan_from_terms(j->gen->mirror, j->mq, j->tr, j->exact_wid, 0, &j->plan); j->planned = 1; }
+}
 
-    /* everything from get_matching_docids to the top-2N cut (squery.c:480-517), on the GPU */
-    m_sqresult_t out;
-    memset(&out, 0, sizeof(out));
-    if (!rc) rc = msq_execute_plan(ctx, mirror, mq, &plan, sq->shard_idx, &out);
-    if (ctx) ctx_release(device, slot);
-
-    if (rc) {
-        M_ERR("gpu squery: shard %d: error %d %s", sq->shard_idx, rc, mgpu_last_error());
+/* m_sqresult_t -> struct squery_result (what form_result and sqresult_free read), release, worker_done */
+static void job_end(struct sq_job *j) {
+    struct squery *sq = j->sq;
+    struct query *q = sq->q;
+    struct squery_result *res = sq->sqres;
+    const int num_facets = q->in->mapping->num_facets;
+    khiter_t k;                                              /* (kh_set assigns to a variable of this name) */
+    if (j->rc) {
+        M_ERR("gpu squery: shard %d: error %d %s", sq->shard_idx, j->rc, mgpu_last_error());
     } else {
         /* all_wordids as process_termresult leaves it (squery.c:56-60,100-105): wid -> distance of every matching word */
-        for (uint32_t i = 0; i < plan.p.num_wids; i++)
-            if (plan.wids[i].dist != 0xFF) kh_set(WID2TYPOS, res->all_wordids, plan.wids[i].wid, plan.wids[i].dist);
-        res->num_hits = (int)out.num_hits;
-        res->rank_count = out.rank_count;
-        res->ranks = (struct docrank *)out.ranks; out.ranks = NULL;          /* identical layout, libc malloc */
+        for (uint32_t i = 0; i < j->plan.p.num_wids; i++)
+            if (j->plan.wids[i].dist != 0xFF) kh_set(WID2TYPOS, res->all_wordids, j->plan.wids[i].wid, j->plan.wids[i].dist);
+        res->num_hits = (int)j->out.num_hits;
+        res->rank_count = j->out.rank_count;
+        res->ranks = (struct docrank *)j->out.ranks; j->out.ranks = NULL;          /* identical layout, libc malloc */
         for (int f = 0; f < num_facets && f < M_MAX_FIELDS; f++) {
             if (!q->cfg.facet_enabled[f]) continue;
-            res->fh[f].rcount = out.rcount[f];
-            res->fc[f] = (struct facet_count *)out.fc[f]; out.fc[f] = NULL;  /* shard_id already stamped */
+            res->fh[f].rcount = j->out.rcount[f];
+            res->fc[f] = (struct facet_count *)j->out.fc[f]; j->out.fc[f] = NULL;  /* shard_id already stamped */
         }
-        if (res->agg) copy_aggs(res->agg, &out);
-        sq->fast_rank = out.fast_rank;
+        if (res->agg) copy_aggs(res->agg, &j->out);
+        sq->fast_rank = j->out.fast_rank;
     }
-    m_sqresult_free(&out);
-    mplan_free(&plan);
-    mq_free(mq);
-    mirror_release(gen);
+    for (int t = 0; t < j->num_terms && t < M_MAX_QTERMS; t++) m_termresult_free(&j->tr[t]);
+    m_sqresult_free(&j->out);
+    if (j->planned) mplan_free(&j->plan);
+    if (j->mq) mq_free(j->mq);
+    mirror_release(j->gen);
     finish(sq);
+}
+
+/* n (query, shard) pairs through the seam together: the host lookups of every pair, ONE mgpu_lookup_terms and ONE
+ * mgpu_execute per device for all of them (everything from get_matching_docids to the top-2N cut, squery.c:480-517),
+ * then every squery_result filled.  The pairs may belong to one query (execute_query's fan-out, query.c:435-452) or to
+ * several (the "requests" array, index.c:1187-1209). */
+void mgpu_shim_execute_squeries(struct squery *sq, int n) {
+    if (n <= 0) return;
+    struct sq_job *jobs = calloc((size_t)n, sizeof(*jobs));
+    mgpu_term_lookup_t *lk = NULL; int nlk = 0, caplk = 0;
+    if (!jobs) { for (int i = 0; i < n; i++) finish(&sq[i]); return; }
+    for (int i = 0; i < n; i++) job_begin(&jobs[i], &sq[i], &lk, &nlk, &caplk);
+    /* devices in use; pairs of one device form one batch */
+    for (int dev = 0; dev < 64; dev++) {
+        int cnt = 0;
+        for (int i = 0; i < n; i++) if (!jobs[i].rc && jobs[i].gen->device == dev) cnt++;
+        if (!cnt) continue;
+        int slot = 0, rc = 0;
+        mgpu_ctx_t *ctx = ctx_acquire(dev, &slot);
+        if (!ctx) rc = MGPU_E_HIP;
+        /* the typo walks of this device's pairs: one call (the lookups of a pair are contiguous in lk) */
+        if (!rc) {
+            int tot = 0;
+            for (int i = 0; i < n; i++) if (!jobs[i].rc && jobs[i].gen->device == dev) tot += jobs[i].num_lookups;
+            if (tot) {
+                mgpu_term_lookup_t *dl = malloc(sizeof(*dl) * (size_t)tot);
+                int *owner = malloc(sizeof(int) * (size_t)tot), *term = malloc(sizeof(int) * (size_t)tot);
+                int at = 0;
+                for (int i = 0; i < n; i++) {
+                    if (jobs[i].rc || jobs[i].gen->device != dev) continue;
+                    for (int x = 0; x < jobs[i].num_lookups; x++) { dl[at] = lk[jobs[i].first_lookup + x]; owner[at] = i; term[at] = jobs[i].lookup_term[x]; at++; }
+                }
+                mgpu_term_hit_t *hits = NULL; uint32_t nh = 0;
+                rc = mgpu_lookup_terms(ctx, dl, tot, &hits, &nh);
+                for (uint32_t h = 0; !rc && h < nh; h++) {
+                    if (hits[h].lookup >= (uint32_t)tot) { rc = MGPU_E_HIP; break; }
+                    m_u32map_t *m = &jobs[owner[hits[h].lookup]].tr[term[hits[h].lookup]].wordids;
+                    /* add_wordid_to_result (dtrie.c:633-640): least distance */
+                    if ((int)hits[h].dist < m_u32map_get(m, hits[h].wid, 0xFF)) m_u32map_set(m, hits[h].wid, (int32_t)hits[h].dist);
+                }
+                mgpu_term_hits_free(hits);
+                free(dl); free(owner); free(term);
+            }
+        }
+        /* plans, then the batch */
+        const mmirror_t **ms = malloc(sizeof(*ms) * (size_t)cnt);
+        const m_query_t **qs = malloc(sizeof(*qs) * (size_t)cnt);
+        const mplan_t **pls = malloc(sizeof(*pls) * (size_t)cnt);
+        int *sidx = malloc(sizeof(int) * (size_t)cnt), *who = malloc(sizeof(int) * (size_t)cnt);
+        m_sqresult_t *outs = calloc((size_t)cnt, sizeof(*outs));
+        int m = 0;
+        for (int i = 0; i < n; i++) {
+            if (jobs[i].rc || jobs[i].gen->device != dev) continue;
+            if (rc) { jobs[i].rc = rc; continue; }
+            job_plan(&jobs[i]);
+            if (jobs[i].rc) continue;
+            ms[m] = jobs[i].gen->mirror; qs[m] = jobs[i].mq; pls[m] = &jobs[i].plan; sidx[m] = jobs[i].sq->shard_idx; who[m] = i; m++;
+        }
+        if (m) {
+            rc = msq_execute_plans(ctx, ms, qs, pls, sidx, m, outs);
+            for (int x = 0; x < m; x++) { if (rc) jobs[who[x]].rc = rc; else jobs[who[x]].out = outs[x]; }
+        }
+        if (ctx) ctx_release(dev, slot);
+        free(ms); free(qs); free(pls); free(sidx); free(who); free(outs);
+    }
+    for (int i = 0; i < n; i++) job_end(&jobs[i]);
+    free(lk);
+    free(jobs);
+}
+
+void execute_squery(void *w) {
+    mgpu_shim_execute_squeries((struct squery *)w, 1);
 }
 
 /* Row f-2, the part that exists: refresh keyed on the commit.  Call where a bulk write ends (sindex.c:246).  When the

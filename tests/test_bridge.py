@@ -26,12 +26,18 @@ def test_shim_compiles_against_reference_headers_and_exports_the_seam():
     assert "warning" not in r.stdout
     nm = subprocess.run(["nm", SHIM_OBJ], stdout=subprocess.PIPE, text=True).stdout
     defined = {l.split()[-1] for l in nm.splitlines() if " T " in l}
-    assert {"execute_squery", "sqresult_free", "mgpu_shim_attach_shard", "mgpu_shim_detach_shard", "mgpu_shim_refresh_shard"} <= defined
+    assert {"execute_squery", "sqresult_free", "mgpu_shim_execute_squeries", "mgpu_shim_attach_shard", "mgpu_shim_detach_shard",
+            "mgpu_shim_refresh_shard"} <= defined
     undefined = {l.split()[-1] for l in nm.splitlines() if " U " in l}
     # host work that stays with the reference, GPU work that goes through the host library; no oracle, no CPU ranking
-    assert {"dtrie_lookup_term", "dtrie_lookup_exact", "mplan_from_terms", "msq_execute_plan", "mmirror_create",
+    assert {"dtrie_lookup_term", "dtrie_lookup_exact", "mplan_from_terms", "msq_execute_plans", "mmirror_create",
             "mgpu_dict_create", "mgpu_lookup_terms"} <= undefined
     assert not {u for u in undefined if u.startswith("orc_") or u in ("perform_ranking", "filter_apply", "rank_sort")}
+    # the replacement query.c: the reference's own file with another execute_query (shim/query_gpu.c)
+    nm2 = subprocess.run(["nm", os.path.join(ROOT, "shim", "_build", "query_gpu.o")], stdout=subprocess.PIPE, text=True).stdout
+    defined2 = {l.split()[-1] for l in nm2.splitlines() if " T " in l}
+    assert {"execute_query", "mgpu_shim_execute_queries", "generate_query_terms", "query_new", "query_free"} <= defined2
+    assert "mgpu_shim_execute_squeries" in {l.split()[-1] for l in nm2.splitlines() if " U " in l}
 
 
 def clone_through_bridge(lib, shard):

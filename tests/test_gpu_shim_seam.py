@@ -37,6 +37,10 @@ def key_of(pq):
 def compare(ix, pqs, tag):
     want = ref_py.run(ix, pqs)
     got = ref_py.run(ix, pqs, gpu=True)
+    compare_lists(pqs, want, got, tag)
+
+
+def compare_lists(pqs, want, got, tag):
     for pq, ws, gs in zip(pqs, want, got):
         key = key_of(pq)
         for s, (w, g) in enumerate(zip(ws, gs)):
@@ -89,3 +93,33 @@ def test_generated_queries_through_the_seam():
         compare(ix, pqs, "custom")
     finally:
         ix.close()
+
+
+def test_mirror_refresh_after_a_second_bulk_write():
+    """Row f-2, the trigger: documents indexed AFTER the mirror was attached (a second si_write_start .. si_write_end on
+    the same LMDB environments and dtrie) are invisible until mgpu_shim_refresh_shard sees the environment's newer
+    transaction id, rebuilds the mirror from a fresh read snapshot and swaps it in; the answers then equal the
+    reference's on the grown shard"""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_parity
+    rng = random.Random(79)
+    ix_ab = fuzz_parity.custom_index(rng, ndocs=1600, shards=2)
+    all_docs = [d for d in sorted((d for sh in ix_ab.docs for d in sh), key=lambda d: d["id"])]
+    ix_a = Index(dict(ix_ab.settings), num_shards=2).add_documents(all_docs[:900])
+    ix_ab2 = Index(dict(ix_ab.settings), num_shards=2).add_documents(all_docs)
+    try:
+        jqs = [dict(j, fullScan=True) for j in fuzz_parity.custom_queries(rng, 60)]
+        pa, pab = [], []
+        for j in jqs:
+            try:
+                a, b = ix_a.query(j), ix_ab2.query(j)
+            except (QueryError, KeyError, ValueError):
+                continue
+            pa.append(a); pab.append(b)
+        w1, w2 = ref_py.run_two_writes(ix_a, ix_ab2, pa, pab)
+        g1, g2 = ref_py.run_two_writes(ix_a, ix_ab2, pa, pab, gpu=True)
+        compare_lists(pa, w1, g1, "before the second write")
+        compare_lists(pab, w2, g2, "after refresh")
+        assert any(x[0]["num_hits"] != y[0]["num_hits"] for x, y in zip(w1, w2)), "the second write changed nothing"
+    finally:
+        ix_a.close(); ix_ab.close(); ix_ab2.close()
