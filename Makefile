@@ -21,14 +21,14 @@ oracle: oracle/liborc.so
 marlin_amd/lib/libmarlin_gpu.so: $(GPU_SRC) $(GPU_HDR)
 	@mkdir -p marlin_amd/lib
 	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Iinclude -Imarlin_amd/csrc \
-	    -o $@ $(GPU_SRC)
+	    -o $@ $(GPU_SRC) -L/opt/rocm/lib -lrccl
 
 # the same library with the checked accessors of the rank / doc-processing kernels compiled in (mgpu_kernels.hip, CK):
 # `make gpu-checked` overwrites libmarlin_gpu.so; run the GPU suite on it, then `make -B gpu` for the product build
 gpu-checked: $(GPU_SRC) $(GPU_HDR)
 	@mkdir -p marlin_amd/lib
 	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DMGPU_CHECKED -Iinclude -Imarlin_amd/csrc \
-	    -o marlin_amd/lib/libmarlin_gpu.so $(GPU_SRC)
+	    -o marlin_amd/lib/libmarlin_gpu.so $(GPU_SRC) -L/opt/rocm/lib -lrccl
 
 marlin_amd/lib/libmarlin_host.so: $(HOST_SRC) $(HOST_HDR) marlin_amd/lib/libmarlin_gpu.so
 	@mkdir -p marlin_amd/lib

@@ -143,7 +143,9 @@ def main():
         return [pool[(step * B + i) % nq_pool] for i in range(B)]
 
     gather = None
-    if world > 1:
+    c_loop = world == 1 or not args.rehearse_gloo      # the native loop (mplan.c); the gloo rehearsal shares one GPU among the
+                                                       # ranks, which RCCL cannot do: it keeps the torch.distributed gather
+    if world > 1 and not c_loop:
         from marlin_amd.dist import ShardGather
         gather = ShardGather(lib, dist, world, rank, B, local, K_TOP, NF, FMAX, NAGG,
                              device=None if args.rehearse_gloo else "cuda:%d" % local_rank, nslots=max(1, args.inflight))
@@ -157,7 +159,7 @@ def main():
     resolved = [eng.resolve(batch_queries(j), device_lookup=True) for j in range(nbatches)]
     t_prepare = time.time() - t0
     # prepared batches (plans built ahead) only for the N > 1 loop, the stage profile and the replay line
-    nprep = nbatches if world > 1 else min(nbatches, 8)
+    nprep = nbatches if not c_loop else min(nbatches, 8)
     prepared = [eng.plan_resolved(resolved[j]) for j in range(nprep)]
 
     F = max(1, args.inflight)
@@ -203,8 +205,8 @@ def main():
 
     def run_steps(first, count):
         """`count` steps with up to F batches in flight (one host thread and one context each)"""
-        if world == 1:
-            # one GPU: the whole loop is native (host threads, contexts, execute + merge: mplan.c)
+        if c_loop:
+            # the whole loop is native (host threads, contexts, plans, execute, [RCCL all-gather,] merge: mplan.c)
             hits, pms = eng.run_pipeline_resolved(resolved, first, count, F)
             plan_ms[0] = pms
             return hits
@@ -242,8 +244,15 @@ def main():
     # the RCCL communicator have been used) whatever --warmup says.  The pipeline's host threads are created
     # here too and stay parked between runs: nothing of this is left for the timed region.
     t0 = time.time()
-    if world == 1:
+    if c_loop:
         eng.warm_pipeline_resolved(resolved, F)
+        if world > 1:
+            # the exchange of (e): rank 0's RCCL id goes round through torch.distributed, everything after that is C
+            idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(eng.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(idt, 0)
+            eng.enable_gather(bytes(idt.cpu().numpy().tobytes()), rank, world, B, K_TOP, NF, FMAX, NAGG, nthreads=F)
     else:
         for slot in range(F):
             for j in range(nprep):
@@ -407,7 +416,8 @@ def main():
                                    "rankBy num desc, top-10, fullScan" % (args.docs, TOTAL_SHARDS),
                        "queries_per_step": B * S, "queries_per_device_batch": B, "device_batches_per_step": S, "batches_in_flight": F, "shards_per_gpu": local, "vocab": VOCAB,
                        "mean_hits_per_query": round(total_hits / max(1, args.steps * S * B), 1),
-                       "distinct_queries": nq_pool, "plans_in_timed_region": world == 1,
+                       "distinct_queries": nq_pool, "plans_in_timed_region": bool(c_loop),
+                       "exchange": None if world == 1 else ("ncclAllGather of result slots from the C pipeline (mgpu_comm_*)" if c_loop else "torch.distributed all_gather (gloo rehearsal)"),
                        "timed_region": "per batch: process_termresult for 128 queries x 8 shards (msq_plan_resolved) + plan lowering + "
                                        "upload + kernels + download + decode + form_result; dictionary lookups resolved before"},
             "plan_build_ms_per_batch": round(plan_ms_batch, 3),

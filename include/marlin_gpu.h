@@ -269,6 +269,32 @@ uint64_t mgpu_dict_bytes(const mgpu_dict_t *d);
 int  mgpu_lookup_terms(mgpu_ctx_t *c, const mgpu_term_lookup_t *lookups, int n, mgpu_term_hit_t **hits, uint32_t *nhits);
 void mgpu_term_hits_free(mgpu_term_hit_t *hits);
 
+/* ------------------------------------------------------------------ (e): the cross-GPU exchange
+ * One process per GPU owns a block of the index's shards; after a batch every process holds fixed-size result slots
+ * for its (query, shard) pairs and ONE all-gather hands every slot to every process, which then merges its share of the
+ * queries (form_result, /root/reference/src/main/query.c:312-383: the reference merges in shared memory after
+ * wait_for_workers, query.c:449).  mgpu_comm_* is that all-gather: RCCL over xGMI, issued from C on a stream of its own.
+ *
+ * mgpu_comm_unique_id: 128 bytes the caller hands to every rank by whatever means it has (rank 0 makes them).
+ * mgpu_comm_create: ncclCommInitRank for `rank` of `world` on `device`; `nslots` buffer sets of up to `max_bytes` per
+ * rank, so that several gathers can be in flight.
+ * mgpu_comm_allgather_begin: copies `bytes` from `send` (host) to the device, all-gathers, copies world * bytes back to
+ * `recv` (host), all enqueued on the comm's stream; returns without waiting.  Every rank must issue its begins in the
+ * same order.  mgpu_comm_allgather_end waits for that slot's copies.  `send` / `recv` should be pinned
+ * (mgpu_host_alloc) so that the copies are asynchronous. */
+typedef struct mgpu_comm mgpu_comm_t;
+#define MGPU_COMM_ID_BYTES 128
+int  mgpu_comm_unique_id(void *id /* [MGPU_COMM_ID_BYTES] */);
+int  mgpu_comm_create(int device, const void *id, int rank, int world, int nslots, size_t max_bytes, mgpu_comm_t **out);
+void mgpu_comm_destroy(mgpu_comm_t *c);
+int  mgpu_comm_rank(const mgpu_comm_t *c);
+int  mgpu_comm_world(const mgpu_comm_t *c);
+int  mgpu_comm_allgather_begin(mgpu_comm_t *c, int slot, const void *send, size_t bytes, void *recv);
+int  mgpu_comm_allgather_end(mgpu_comm_t *c, int slot);
+/* pinned host memory for the buffers above */
+void *mgpu_host_alloc(size_t bytes);
+void  mgpu_host_free(void *p);
+
 #ifdef __cplusplus
 }
 #endif

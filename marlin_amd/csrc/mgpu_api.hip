@@ -1758,3 +1758,89 @@ extern "C" int mgpu_lookup_terms(mgpu_ctx_t *c, const mgpu_term_lookup_t *lookup
     *nhits = total;
     return MGPU_OK;
 }
+
+// ------------------------------------------------------------------ (e): RCCL all-gather of result slots
+#include <rccl/rccl.h>
+struct mgpu_comm {
+    int device, rank, world, nslots;
+    size_t max_bytes;
+    ncclComm_t comm;
+    hipStream_t stream;
+    std::vector<char *> d_send, d_recv;
+    std::vector<hipEvent_t> done;
+};
+#define NCCLCHK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) return fail(MGPU_E_HIP, std::string(#x) + ": " + ncclGetErrorString(r_)); } while (0)
+
+extern "C" int mgpu_comm_unique_id(void *id) {
+    if (!id) return fail(MGPU_E_ARG, "null argument");
+    static_assert(sizeof(ncclUniqueId) == MGPU_COMM_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId u;
+    NCCLCHK(ncclGetUniqueId(&u));
+    memcpy(id, &u, sizeof(u));
+    return MGPU_OK;
+}
+
+extern "C" void mgpu_comm_destroy(mgpu_comm_t *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (char *p : c->d_send) if (p) (void)hipFree(p);
+    for (char *p : c->d_recv) if (p) (void)hipFree(p);
+    for (hipEvent_t e : c->done) (void)hipEventDestroy(e);
+    if (c->comm) (void)ncclCommDestroy(c->comm);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int mgpu_comm_create(int device, const void *id, int rank, int world, int nslots, size_t max_bytes, mgpu_comm_t **out) {
+    if (!id || !out || world < 1 || rank < 0 || rank >= world || nslots < 1 || nslots > 256 || !max_bytes) return fail(MGPU_E_ARG, "bad argument");
+    HIPCHK(hipSetDevice(device));
+    mgpu_comm *c = new mgpu_comm();
+    c->device = device; c->rank = rank; c->world = world; c->nslots = nslots; c->max_bytes = max_bytes;
+    c->comm = nullptr; c->stream = nullptr;
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof(u));
+    ncclResult_t nr = ncclCommInitRank(&c->comm, world, u, rank);
+    if (nr != ncclSuccess) { c->comm = nullptr; mgpu_comm_destroy(c); return fail(MGPU_E_HIP, std::string("ncclCommInitRank: ") + ncclGetErrorString(nr)); }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { c->stream = nullptr; mgpu_comm_destroy(c); return fail(MGPU_E_HIP, "hipStreamCreate"); }
+    for (int i = 0; i < nslots; i++) {
+        char *a = nullptr, *b = nullptr; hipEvent_t e;
+        if (hipMalloc((void **)&a, max_bytes) != hipSuccess || hipMalloc((void **)&b, max_bytes * (size_t)world) != hipSuccess ||
+            hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+            if (a) (void)hipFree(a);
+            if (b) (void)hipFree(b);
+            mgpu_comm_destroy(c);
+            return fail(MGPU_E_HIP, "comm buffers");
+        }
+        c->d_send.push_back(a); c->d_recv.push_back(b); c->done.push_back(e);
+    }
+    *out = c;
+    return MGPU_OK;
+}
+
+extern "C" int mgpu_comm_rank(const mgpu_comm_t *c) { return c ? c->rank : -1; }
+extern "C" int mgpu_comm_world(const mgpu_comm_t *c) { return c ? c->world : 0; }
+
+extern "C" int mgpu_comm_allgather_begin(mgpu_comm_t *c, int slot, const void *send, size_t bytes, void *recv) {
+    if (!c || slot < 0 || slot >= c->nslots || !send || !recv || !bytes) return fail(MGPU_E_ARG, "bad argument");
+    if (bytes > c->max_bytes) return fail(MGPU_E_LIMIT, "gather larger than the comm's buffers");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(c->d_send[slot], send, bytes, hipMemcpyHostToDevice, c->stream));
+    NCCLCHK(ncclAllGather(c->d_send[slot], c->d_recv[slot], bytes, ncclUint8, c->comm, c->stream));
+    HIPCHK(hipMemcpyAsync(recv, c->d_recv[slot], bytes * (size_t)c->world, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipEventRecord(c->done[slot], c->stream));
+    return MGPU_OK;
+}
+
+extern "C" int mgpu_comm_allgather_end(mgpu_comm_t *c, int slot) {
+    if (!c || slot < 0 || slot >= c->nslots) return fail(MGPU_E_ARG, "bad argument");
+    HIPCHK(hipEventSynchronize(c->done[slot]));
+    return MGPU_OK;
+}
+
+extern "C" void *mgpu_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+extern "C" void mgpu_host_free(void *p) { if (p) (void)hipHostFree(p); }

@@ -120,10 +120,39 @@ class GpuEngine:
         self._pipe = None
         self._pipe_n = 0
 
+    # ---- several GPUs: one process per GPU, the pipeline's batches end with an RCCL all-gather
+    def comm_unique_id(self):
+        """128 bytes rank 0 makes and every rank needs (hand them round with whatever the launcher has)"""
+        buf = C.create_string_buffer(128)
+        rc = self.lib.mgpu_comm_unique_id(buf)
+        if rc:
+            raise GpuError("mgpu_comm_unique_id: %d %s" % (rc, self.lib.mgpu_last_error().decode()))
+        return buf.raw
+
+    def enable_gather(self, comm_id, rank, world, queries_per_batch, k_top, num_facets, fmax, num_aggs, nthreads=None):
+        """from now on run_pipeline / run_pipeline_resolved end every batch with ONE all-gather of its result slots over
+        RCCL, issued by the pipeline's own threads (mplan.c:pipe_gather), and merge this rank's share of the queries:
+        the returned hit sums are per rank"""
+        pipe = self._pipeline(nthreads)
+        pairs = queries_per_batch * self.index.num_shards
+        slot_b = self.lib.m_slot_bytes(k_top, num_facets, fmax, num_aggs)
+        comm = C.c_void_p()
+        idb = C.create_string_buffer(bytes(comm_id), 128)
+        rc = self.lib.mgpu_comm_create(self.device, idb, rank, world, self._pipe_n, pairs * slot_b, C.byref(comm))
+        if rc:
+            raise GpuError("mgpu_comm_create: %d %s" % (rc, self.lib.mgpu_last_error().decode()))
+        self._comm = comm
+        rc = self.lib.msq_pipeline_set_gather(pipe, comm, pairs, k_top, num_facets, fmax, num_aggs)
+        if rc:
+            raise GpuError("msq_pipeline_set_gather: %d %s" % (rc, self.lib.msq_pipeline_error(pipe).decode()))
+
     def close(self):
         if self._pipe is not None:
             self.lib.msq_pipeline_destroy(self._pipe)
             self._pipe = None
+        if getattr(self, "_comm", None) is not None:
+            self.lib.mgpu_comm_destroy(self._comm)
+            self._comm = None
         for m in self.mirrors:
             self.lib.mmirror_destroy(m)
         self.mirrors = []

@@ -288,6 +288,16 @@ def load():
         "msq_pipeline_warm_resolved": (ci, [vp, C.POINTER(vp), ci]),
         "msq_pipeline_run_resolved": (ci, [vp, C.POINTER(vp), ci, ci, ci, C.POINTER(C.c_long)]),
         "msq_pipeline_plan_ms": (cd, [vp]),
+        "msq_pipeline_set_gather": (ci, [vp, vp, ci, ci, ci, ci, ci]),
+        "mgpu_comm_unique_id": (ci, [vp]),
+        "mgpu_comm_create": (ci, [ci, vp, ci, ci, ci, C.c_size_t, C.POINTER(vp)]),
+        "mgpu_comm_destroy": (None, [vp]),
+        "mgpu_comm_rank": (ci, [vp]),
+        "mgpu_comm_world": (ci, [vp]),
+        "mgpu_comm_allgather_begin": (ci, [vp, ci, vp, C.c_size_t, vp]),
+        "mgpu_comm_allgather_end": (ci, [vp, ci]),
+        "mgpu_host_alloc": (vp, [C.c_size_t]),
+        "mgpu_host_free": (None, [vp]),
         "msq_pipeline_destroy": (None, [vp]),
         # GPU C ABI (include/marlin_gpu.h), reached through the same process image
         "mgpu_last_error": (C.c_char_p, []),

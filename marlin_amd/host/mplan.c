@@ -831,6 +831,12 @@ struct msq_pipeline {
     double plan_ms[64];                   /* per thread: wall time spent building plans in the last run */
     long hits[64]; int rc[64];
     char err[256];
+    /* several GPUs: this process owns `gl_shards` of the index's shards; after a batch its result slots
+     * are all-gathered over RCCL (mgpu_comm_*, issued from these threads in step order) and it merges its share of the
+     * batch's queries: query rank, rank + world, ... */
+    mgpu_comm_t *comm; int g_k, g_nf, g_fmax, g_nagg, g_pairs; size_t g_slot_b;
+    uint8_t *g_send[128], *g_recv[128];   /* per context: pinned slot buffers */
+    pthread_mutex_t g_mu; pthread_cond_t g_cv; long g_turn; int g_fail;
 };
 typedef struct { msq_pipeline_t *p; int t; } pipe_arg_t;
 
@@ -842,14 +848,53 @@ static void pipe_fail(msq_pipeline_t *p, int t, int rc) {
     p->rc[t] = rc;
 }
 
+/* the cross-GPU step of batch `step` (context slot ci): slots packed, all-gathered in step order, this rank's share of
+ * the queries unpacked and merged.  Returns the share's summed totalHits through *hits. */
+static int pipe_gather(msq_pipeline_t *p, int ci, long step, const msq_prepared_t *pp, m_sqresult_t *outs, long *hits) {
+    const int world = mgpu_comm_world(p->comm), rank = mgpu_comm_rank(p->comm);
+    if (pp->n != p->g_pairs) return MGPU_E_ARG;
+    for (int i = 0; i < pp->n; i++) for (int a = 0; a < outs[i].num_aggs; a++)
+        if (outs[i].aggs[a].type == MA_CARDINALITY) return MGPU_E_UNSUPPORTED;      /* variable-length id sets: marlin_amd/dist.py's second gather */
+    m_slot_pack_batch(outs, pp->n, p->g_k, p->g_nf, p->g_fmax, p->g_nagg, p->g_send[ci]);
+    /* every rank issues its gathers in step order, whatever its threads do */
+    pthread_mutex_lock(&p->g_mu);
+    while (p->g_turn != step && !p->g_fail) pthread_cond_wait(&p->g_cv, &p->g_mu);
+    int rc = p->g_fail ? MGPU_E_HIP : mgpu_comm_allgather_begin(p->comm, ci, p->g_send[ci], (size_t)pp->n * p->g_slot_b, p->g_recv[ci]);
+    if (rc) p->g_fail = 1; else p->g_turn = step + 1;
+    pthread_cond_broadcast(&p->g_cv);
+    pthread_mutex_unlock(&p->g_mu);
+    if (rc) return rc;
+    if ((rc = mgpu_comm_allgather_end(p->comm, ci))) return rc;
+    const int total = world * pp->num_shards;
+    int mine = 0;
+    for (int q = rank; q < pp->nq; q += world) mine++;
+    if (!mine) { *hits = 0; return 0; }
+    m_sqresult_t *sq = calloc((size_t)mine * (size_t)total, sizeof(*sq));
+    const m_query_t **qs = malloc(sizeof(*qs) * (size_t)mine);
+    if (!sq || !qs) { free(sq); free(qs); return MGPU_E_LIMIT; }
+    m_slot_unpack_gathered_subset(p->g_recv[ci], world, pp->nq, pp->num_shards, p->g_k, p->g_nf, p->g_fmax, p->g_nagg, rank, world, sq);
+    for (int i = 0; i < mine; i++) qs[i] = pp->queries[rank + i * world];
+    *hits = m_form_result_batch(qs, sq, mine, total, NULL, 0);
+    m_sqresult_free_batch(sq, mine * total);
+    free(sq); free(qs);
+    return 0;
+}
+
 /* wait for the batch in flight on ctx, merge it (form_result) */
-static int pipe_collect(msq_pipeline_t *p, int t, mgpu_ctx_t *ctx, const msq_prepared_t *pp, pipe_trace_t *tr) {
+static int pipe_collect(msq_pipeline_t *p, int t, int ci, long step, mgpu_ctx_t *ctx, const msq_prepared_t *pp, pipe_trace_t *tr) {
     m_sqresult_t *outs = calloc((size_t)(pp->n ? pp->n : 1), sizeof(m_sqresult_t));
     if (!outs) { p->rc[t] = -1; return -1; }
     if (tr) tr->col0 = pipe_now() - p->t_run0;
     int rc = msq_collect_prepared(ctx, pp, outs);
     if (tr) { tr->col1 = pipe_now() - p->t_run0; mgpu_last_timing(ctx, &tr->gpu_ms, NULL); }
-    if (!rc) p->hits[t] += m_form_result_batch((const m_query_t *const *)pp->queries, outs, pp->nq, pp->num_shards, NULL, 0);
+    if (!rc && p->comm && step >= 0) {
+        long h = 0;
+        rc = pipe_gather(p, ci, step, pp, outs, &h);
+        if (!rc) p->hits[t] += h;
+    } else if (!rc && !p->comm) p->hits[t] += m_form_result_batch((const m_query_t *const *)pp->queries, outs, pp->nq, pp->num_shards, NULL, 0);
+    if (rc && p->comm) {                                      /* nobody may wait for a turn that will not come */
+        pthread_mutex_lock(&p->g_mu); p->g_fail = 1; pthread_cond_broadcast(&p->g_cv); pthread_mutex_unlock(&p->g_mu);
+    }
     m_sqresult_free_batch(outs, pp->n);
     free(outs);
     if (tr) {
@@ -886,12 +931,13 @@ static void pipe_steps(msq_pipeline_t *p, int t) {
                 const msq_prepared_t *pp = pipe_batch(p, t, 2 * t + k, i, &rc);
                 if (!rc) rc = msq_submit_prepared(cx[k], pp);
                 if (rc) { pipe_fail(p, t, rc); return; }
-                if (pipe_collect(p, t, cx[k], pp, NULL)) return;
+                if (pipe_collect(p, t, 2 * t + k, -1, cx[k], pp, NULL)) return;       /* warm-up: no exchange */
             }
         return;
     }
     /* steps t, t + nthreads, ...: the next step is submitted before the current one is collected */
     const msq_prepared_t *inflight[2] = { NULL, NULL };
+    long inflight_step[2] = { -1, -1 };
     pipe_trace_t tr[2];
     int slot = 0;
     for (int i = t; i < p->count || inflight[0] || inflight[1]; i += p->nthreads) {
@@ -902,14 +948,14 @@ static void pipe_steps(msq_pipeline_t *p, int t) {
             if (!rc) rc = msq_submit_prepared(cx[slot], pp);
             tr[slot].sub1 = pipe_now() - p->t_run0;
             if (rc) { pipe_fail(p, t, rc); break; }
-            inflight[slot] = pp;
+            inflight[slot] = pp; inflight_step[slot] = i;
         }
         /* collect the older batch: the other slot when there are two, else this one */
         const int older = ncx == 2 ? slot ^ 1 : slot;
         if (inflight[older]) {
             const msq_prepared_t *pp = inflight[older];
             inflight[older] = NULL;
-            if (pipe_collect(p, t, cx[older], pp, p->trace_on ? &tr[older] : NULL)) break;
+            if (pipe_collect(p, t, 2 * t + older, inflight_step[older], cx[older], pp, p->trace_on ? &tr[older] : NULL)) break;
         }
         if (ncx == 2) slot ^= 1;
     }
@@ -947,6 +993,7 @@ int msq_pipeline_create(mgpu_ctx_t *const *ctxs, int nctx, msq_pipeline_t **out)
     p->trace_on = getenv("MSQ_PIPE_TRACE") != NULL;
     if (p->trace_on) p->trace = calloc(PIPE_TRACE_MAX, sizeof(pipe_trace_t));
     pthread_mutex_init(&p->mu, NULL); pthread_cond_init(&p->go, NULL); pthread_cond_init(&p->done, NULL);
+    pthread_mutex_init(&p->g_mu, NULL); pthread_cond_init(&p->g_cv, NULL);
     for (int t = 0; t < nctx; t++) p->ctx[t] = ctxs[t];
     for (int t = 0; t < nthreads; t++) {
         pipe_arg_t *a = malloc(sizeof(*a));
@@ -964,6 +1011,7 @@ static int pipe_dispatch(msq_pipeline_t *p, const msq_prepared_t *const *preps, 
     p->preps = preps; p->res = res; p->nprep = nprep; p->first = first; p->count = count; p->every = every;
     p->err[0] = 0;
     p->ntrace = 0; p->t_run0 = pipe_now();
+    p->g_turn = 0; p->g_fail = 0;
     p->pending = p->nthreads;
     p->gen++;
     pthread_cond_broadcast(&p->go);
@@ -1007,6 +1055,33 @@ double msq_pipeline_plan_ms(const msq_pipeline_t *p) {
     return t;
 }
 
+/* Several GPUs: from now on every batch of the loop ends with the all-gather of its result slots over `comm` (created
+ * with at least as many slots as the pipeline has contexts) and this rank merges its share of the queries.  `pairs` =
+ * (query, shard) pairs of a batch on this rank; k / num_facets / fmax / num_aggs = the slot shape (m_slot_bytes), the
+ * same on every rank.  One gather per context slot runs here, in slot order, so that the communicator and the buffers
+ * have been used before a caller starts a clock.  A batch with a cardinality aggregation is refused
+ * (MGPU_E_UNSUPPORTED): its id sets are variable-length (marlin_amd/dist.py carries them in a second gather). */
+int msq_pipeline_set_gather(msq_pipeline_t *p, mgpu_comm_t *comm, int pairs, int k, int num_facets, int fmax, int num_aggs) {
+    if (!p || !comm || pairs < 1) return MGPU_E_ARG;
+    const int world = mgpu_comm_world(comm);
+    p->g_k = k; p->g_nf = num_facets; p->g_fmax = fmax; p->g_nagg = num_aggs; p->g_pairs = pairs;
+    p->g_slot_b = m_slot_bytes(k, num_facets, fmax, num_aggs);
+    const size_t n = (size_t)pairs * p->g_slot_b;
+    for (int i = 0; i < p->nctx; i++) {
+        mgpu_host_free(p->g_send[i]); mgpu_host_free(p->g_recv[i]);
+        p->g_send[i] = mgpu_host_alloc(n); p->g_recv[i] = mgpu_host_alloc(n * (size_t)world);
+        if (!p->g_send[i] || !p->g_recv[i]) return MGPU_E_LIMIT;
+        memset(p->g_send[i], 0, n);
+    }
+    for (int i = 0; i < p->nctx; i++) {
+        int rc = mgpu_comm_allgather_begin(comm, i, p->g_send[i], n, p->g_recv[i]);
+        if (!rc) rc = mgpu_comm_allgather_end(comm, i);
+        if (rc) { snprintf(p->err, sizeof(p->err), "%s", mgpu_last_error()); return rc; }
+    }
+    p->comm = comm;
+    return 0;
+}
+
 const char *msq_pipeline_error(const msq_pipeline_t *p) { return p ? p->err : ""; }
 
 void msq_pipeline_destroy(msq_pipeline_t *p) {
@@ -1018,6 +1093,8 @@ void msq_pipeline_destroy(msq_pipeline_t *p) {
     for (int t = 0; t < p->nthreads; t++) pthread_join(p->th[t], NULL);
     pthread_mutex_destroy(&p->mu); pthread_cond_destroy(&p->go); pthread_cond_destroy(&p->done);
     for (int i = 0; i < 128; i++) msq_prepared_free(p->slot_pp[i]);
+    for (int i = 0; i < 128; i++) { mgpu_host_free(p->g_send[i]); mgpu_host_free(p->g_recv[i]); }
+    pthread_mutex_destroy(&p->g_mu); pthread_cond_destroy(&p->g_cv);
     free(p->trace);
     free(p);
 }

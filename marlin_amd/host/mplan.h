@@ -122,6 +122,9 @@ int  msq_pipeline_run(msq_pipeline_t *p, const msq_prepared_t *const *preps, int
 int  msq_pipeline_warm_resolved(msq_pipeline_t *p, const msq_resolved_t *const *res, int nres);
 int  msq_pipeline_run_resolved(msq_pipeline_t *p, const msq_resolved_t *const *res, int nres, int first, int count, long *hits_out);
 double msq_pipeline_plan_ms(const msq_pipeline_t *p);
+/* several GPUs: every batch of the loop ends with ONE RCCL all-gather of its result slots, issued from the pipeline's
+ * threads in step order; the rank merges queries rank, rank + world, ... of each batch (mplan.c) */
+int  msq_pipeline_set_gather(msq_pipeline_t *p, mgpu_comm_t *comm, int pairs, int k, int num_facets, int fmax, int num_aggs);
 const char *msq_pipeline_error(const msq_pipeline_t *p);
 void msq_pipeline_destroy(msq_pipeline_t *p);
 

@@ -69,3 +69,36 @@ def test_gather_on_device_from_worker_threads(tmp_path):
     r = json.loads(line[0][7:])
     assert r["direct"][0]["total"] > 0
     assert r["t0"] == r["direct"] and r["t1"] == r["direct"]
+
+
+def test_rccl_gather_from_the_c_pipeline():
+    """DESIGN.md (e) in C: the serving loop's own threads pack the result slots, issue ncclAllGather (mgpu_comm_*, a
+    ONE-rank communicator on the one GPU of the box) in step order and merge the rank's share of the queries.  Same
+    hit sums as the loop without the exchange, several passes, batches of different queries in flight; a batch with a
+    cardinality aggregation is refused, not mis-merged."""
+    from marlin_amd import GpuEngine, GpuError, Index
+    from test_dist_gloo import corpus, QUERIES
+    ix = Index(corpus()[0], num_shards=2).add_documents(corpus()[1])
+    eng = GpuEngine(ix, device=0, num_ctx=4)
+    try:
+        plain = [q for q in QUERIES if "cardinality" not in str(q)]
+        pqs = [ix.query(dict(q, fullScan=True)) for q in plain]
+        batches = [pqs, pqs[::-1], pqs[1:] + pqs[:1]]
+        ress = [eng.resolve(b) for b in batches]
+        eng.warm_pipeline_resolved(ress, 4)
+        want, _ = eng.run_pipeline_resolved(ress, 0, 11, 4)
+        assert want > 0
+        eng.enable_gather(eng.comm_unique_id(), 0, 1, len(pqs), 100, len(ix.facets), 40, 4, nthreads=4)
+        for _ in range(2):
+            got, _ = eng.run_pipeline_resolved(ress, 0, 11, 4)
+            assert got == want
+        card = [ix.query(dict(q, fullScan=True)) for q in QUERIES if "cardinality" in str(q)][:1] * len(pqs)
+        rc = eng.resolve(card)
+        with pytest.raises(GpuError):
+            eng.run_pipeline_resolved([rc], 0, 2, 4)
+        got, _ = eng.run_pipeline_resolved(ress, 0, 5, 4)          # the loop is usable after the refusal
+        assert got > 0
+        for r in ress + [rc]:
+            eng.free_resolved(r)
+    finally:
+        eng.close(); ix.close()
