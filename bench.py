@@ -159,7 +159,7 @@ def main():
     resolved = [eng.resolve(batch_queries(j), device_lookup=True) for j in range(nbatches)]
     t_prepare = time.time() - t0
     # prepared batches (plans built ahead) only for the N > 1 loop, the stage profile and the replay line
-    nprep = nbatches if not c_loop else min(nbatches, 8)
+    nprep = nbatches        # all of them: the stage profile below averages over the same batches the timed loop cycles
     prepared = [eng.plan_resolved(resolved[j]) for j in range(nprep)]
 
     F = max(1, args.inflight)
@@ -319,22 +319,17 @@ def main():
             eng.free_prepared(pr)
         lat_dev.sort()
 
-    # ---- the same batches with the term lookup inside the loop (typo walks on the device, row f-1): one batch at a time,
-    # prepare (device lookups + plan building on the host's threads) -> execute -> merge
-    qps_lookup = None
+    # ---- the same stream with the WHOLE of lookup_terms inside the loop (row f-1): every step resolves its 128 queries x
+    # shards (typo walks on the device: signature filter + walk of the candidates, on the step's own context; exact
+    # descents on the host), builds the plans, executes and merges -- the same native pipeline, F batches in flight
+    qps_lookup, lookup_ms_batch = None, None
     if world == 1 and not args.no_latency:
-        nb = 6
-        qarrs = [(C.POINTER(ffi.Query) * B)(*[p.q for p in batch_queries(j)]) for j in range(nb)]
-        for j in range(nb + 1):
-            if j == 1:
-                torch.cuda.synchronize(); t0b = time.perf_counter()         # batch 0 warms the lookup buffers
-            pqs_j = batch_queries(j % nb)
-            pr = eng.prepare(pqs_j, device_lookup=True)
-            o = eng.execute_prepared(pr)
-            lib.m_form_result_batch(qarrs[j % nb], o, B, local, None, 0)
-            eng.free_raw(o)
-            eng.free_prepared(pr)
-        qps_lookup = nb * B / (time.perf_counter() - t0b)
+        eng.run_pipeline_queries(pool, B, 0, 2 * F, F)                  # the lookup buffers of every context
+        torch.cuda.synchronize(); t0b = time.perf_counter()
+        nlk = 2 * S
+        _, lkms, _ = eng.run_pipeline_queries(pool, B, 0, nlk, F)
+        qps_lookup = nlk * B / (time.perf_counter() - t0b)
+        lookup_ms_batch = lkms / nlk
 
     # ---- roofline of the dominant kernel stage: HIP events on the launch stream, profiled batches
     roof = None
@@ -342,7 +337,7 @@ def main():
     eng.set_profiling(True)
     acc = {}
     host_acc = {}
-    nprof = min(8, nprep) if nprep > 2 else 5
+    nprof = nprep if nprep > 2 else 5
     for s in range(nprof):
         o = eng.execute_prepared(prepared[s % nprep])
         eng.free_raw(o)
@@ -362,17 +357,22 @@ def main():
     KERNELS = {"rank": "k_rank_tile + k_rank_overflow", "select": "k_select_first + k_select_mid (+ k_select_items, k_select_final)", "formula+compact": "k_formula + k_order + k_order_copy",
                "facets+aggs": "k_docproc + k_aggfinal", "facet-keys": "k_fkeys + k_card + k_facet_hash", "scatter": "k_scatter_list"}
     # HBM traffic of the dominant kernel comes from separate PMC passes (rocprofv3 cannot run inside the
-    # timed program): profiles/r02_pmc_fetch_write_per_launch.json, same batch size and queries
-    traffic = None
+    # timed program): a committed file, NOT a measurement of this run -- `traffic_source` says so in the line
+    traffic, traffic_src = None, None
+    PMC_FILE = "profiles/r03_pmc_fetch_write_per_launch.json"
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_fetch_write_per_launch.json")) as f:
+        with open(os.path.join(ROOT, PMC_FILE)) as f:
             pm = json.load(f)
         if dom == "rank" and B == 128 and world == 1 and args.docs == 10_000_000:
-            traffic = pm["kernels"]["k_rank_tile"]["hbm_bytes_per_launch"] + pm["kernels"]["k_rank_overflow"]["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
+            kk = pm["kernels"]
+            rk = [k for k in kk if "k_rank_tile" in k][0]
+            traffic = kk[rk]["hbm_bytes_per_launch"] + kk["k_rank_overflow"]["hbm_bytes_per_launch"]
+            traffic_src = ("constant read from the committed %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                           "workload taken earlier with tools/gpu_profile.sh), not measured in this run" % PMC_FILE)
+    except (OSError, KeyError, ValueError, IndexError):
         pass
     roof = {"bound": "hbm", "kernel": KERNELS.get(dom, dom), "stage": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "launch_ms": round(acc[dom][0] / nprof, 4), "algorithmic_MB_per_launch": round(acc[dom][1] / nprof / 1e6, 3)}
 
     # ---- CPU baseline: the C oracle (port of the reference's execute_squery) on this host, 1 core
@@ -429,6 +429,7 @@ def main():
                            "with_device_term_lookup_p50": round(lat_dev[len(lat_dev) // 2], 3),
                            "with_device_term_lookup_p99": round(lat_dev[int(len(lat_dev) * 0.99)], 3)} if lat else None,
             "with_device_term_lookup_qps": round(qps_lookup, 1) if qps_lookup else None,
+            "lookup_ms_per_batch": round(lookup_ms_batch, 3) if lookup_ms_batch else None,
             "stages": stage_tab,
             "host_ms_per_step": {k: round(v, 3) for k, v in host_acc.items()},
             "setup_s": {"build_shards": round(t_build, 1), "mirror": round(t_mirror, 1), "term_lookup": round(t_prepare, 2),

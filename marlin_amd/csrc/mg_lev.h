@@ -110,4 +110,35 @@ MG_UNROLL
     return prefix ? best : MG_LEV_NOMATCH;
 }
 
+// ---- signatures: a necessary condition for a match, from 4 bytes per word.
+// An edit script of cost <= k between the term and the word (or, for a prefix term, a prefix of the word) changes the
+// SET of characters by at most k removals and k additions: every insertion, deletion or substitution removes at most
+// one character class from the set and adds at most one, a transposition none.  The walk's distance, where it is <= k,
+// is the cost of such a script (band and early stops only take matches away), so a word whose class set lacks more than
+// k of the term's classes cannot match -- and, without the prefix flag, neither can one that has more than k classes the
+// term lacks or whose length differs by more than k.  With the prefix flag the word must reach depth tlen - k.
+// Bits 0..23: classes (code point % 24) present; bits 24..31: min(length, 255).
+#define MG_LEV_SIG_CLASSES 24u
+template <class Ptr>
+MG_HD uint32_t mg_lev_sig(Ptr s, int len) {
+    uint32_t m = 0;
+    for (int i = 0; i < len; i++) m |= 1u << ((uint32_t)s[i] % MG_LEV_SIG_CLASSES);
+    return m | ((uint32_t)(len > 255 ? 255 : len) << 24);
+}
+MG_HD int mg_lev_popc(uint32_t x) {
+#ifdef __HIP_DEVICE_COMPILE__
+    return __popc(x);
+#else
+    return __builtin_popcount(x);
+#endif
+}
+// false only if mg_lev_word(term, tlen, k, prefix, word, wlen) is MG_LEV_NOMATCH for every word with signature wsig
+MG_HD bool mg_lev_sig_pass(uint32_t tsig, int k, int prefix, uint32_t wsig) {
+    const int tlen = (int)(tsig >> 24), wlen = (int)(wsig >> 24);       // tlen <= 127 (MGPU_MAX_TERM_LEN); wlen 255 = "255 or more"
+    const uint32_t tm = tsig & 0xFFFFFFu, wm = wsig & 0xFFFFFFu;
+    // branch-free: the prefix flag only lifts the two bounds that hold for whole words
+    const int revk = prefix ? 32 : k, maxlen = prefix ? 255 : tlen + k;
+    return (mg_lev_popc(tm & ~wm) <= k) & (mg_lev_popc(wm & ~tm) <= revk) & (wlen >= tlen - k) & (wlen <= maxlen);
+}
+
 #endif

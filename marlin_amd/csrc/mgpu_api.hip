@@ -42,8 +42,8 @@ void mgk_row_op(hipStream_t st, const unsigned long long *a, const unsigned long
 void mgk_scatter_list(hipStream_t st, const uint32_t *src, uint64_t n, unsigned long long *dst);
 void mgk_fetch(hipStream_t st, void *dst, const void *src_pinned, size_t bytes);
 void mgk_facet_hash(hipStream_t st, const SelJob *jobs, const void *outs, const uint32_t *list, const uint32_t *count, uint32_t cap);
-void mgk_term_scan(hipStream_t st, const TermJob *jobs, uint32_t njobs, uint32_t max_words, const uint32_t *term_chars,
-                   uint32_t *hits, uint32_t *count, uint32_t cap);
+void mgk_term_scan(hipStream_t st, const TermJob *jobs, const TermDict *dicts, uint32_t ndicts, uint32_t max_words, const uint32_t *term_chars,
+                   uint2 *cand, uint32_t cand_cap, uint32_t *hits, uint32_t *counts, uint32_t cap);
 }
 
 // Scratch of mgpu_posting_op_noalloc (include/marlin_gpu.h): two operand rows, the result row and the cardinality
@@ -488,6 +488,7 @@ struct mgpu_ctx {
     char *lk_in = nullptr; size_t lk_in_cap = 0;
     uint32_t *lk_hits = nullptr; uint32_t lk_hits_cap = 0;
     uint32_t *lk_count = nullptr;
+    uint2 *lk_cand = nullptr; uint32_t lk_cand_cap = 0;      // (job, word) pairs the signature filter let through
     hipEvent_t ev[MGPU_NUM_STAGES + 1];
     int profiling;
     float stage_ms[MGPU_NUM_STAGES];
@@ -541,6 +542,7 @@ extern "C" void mgpu_ctx_destroy(mgpu_ctx_t *c) {
     if (c->lk_in) (void)hipFree(c->lk_in);
     if (c->lk_hits) (void)hipFree(c->lk_hits);
     if (c->lk_count) (void)hipFree(c->lk_count);
+    if (c->lk_cand) (void)hipFree(c->lk_cand);
     for (int i = 0; i <= MGPU_NUM_STAGES; i++) (void)hipEventDestroy(c->ev[i]);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1662,6 +1664,7 @@ extern "C" int mgpu_posting_op_noalloc(mgpu_ctx_t *c, mgpu_shard_t *s, int op, u
 struct mgpu_dict {
     int device;
     uint32_t *chars = nullptr, *off = nullptr, *wid = nullptr;
+    uint32_t *sig = nullptr;                         // mg_lev_sig per word: what k_term_filter reads
     uint32_t nwords = 0; uint64_t nchars = 0;
 };
 
@@ -1684,6 +1687,12 @@ extern "C" int mgpu_dict_create(int device, const uint32_t *chars, const uint32_
     if (nchars && (e = hipMemcpy(d->chars, chars, nchars * 4, hipMemcpyHostToDevice)) != hipSuccess) return bail(e);
     if ((e = hipMemcpy(d->off, word_off, ((size_t)num_words + 1) * 4, hipMemcpyHostToDevice)) != hipSuccess) return bail(e);
     if (num_words && (e = hipMemcpy(d->wid, word_wid, (size_t)num_words * 4, hipMemcpyHostToDevice)) != hipSuccess) return bail(e);
+    {
+        std::vector<uint32_t> sig((size_t)num_words + 1, 0u);
+        for (uint32_t i = 0; i < num_words; i++) sig[i] = mg_lev_sig(chars + word_off[i], (int)std::min<uint32_t>(word_off[i + 1] - word_off[i], 1u << 20));
+        if ((e = hipMalloc((void **)&d->sig, ((size_t)num_words + 1) * 4)) != hipSuccess) return bail(e);
+        if ((e = hipMemcpy(d->sig, sig.data(), ((size_t)num_words + 1) * 4, hipMemcpyHostToDevice)) != hipSuccess) return bail(e);
+    }
     *out = d;
     return MGPU_OK;
 }
@@ -1694,10 +1703,11 @@ extern "C" void mgpu_dict_destroy(mgpu_dict_t *d) {
     if (d->chars) (void)hipFree(d->chars);
     if (d->off) (void)hipFree(d->off);
     if (d->wid) (void)hipFree(d->wid);
+    if (d->sig) (void)hipFree(d->sig);
     delete d;
 }
 
-extern "C" uint64_t mgpu_dict_bytes(const mgpu_dict_t *d) { return d ? (d->nchars + 4) * 4 + ((uint64_t)d->nwords + 1) * 8 : 0; }
+extern "C" uint64_t mgpu_dict_bytes(const mgpu_dict_t *d) { return d ? (d->nchars + 4) * 4 + ((uint64_t)d->nwords + 1) * 12 : 0; }
 
 extern "C" void mgpu_term_hits_free(mgpu_term_hit_t *hits) { free(hits); }
 
@@ -1708,45 +1718,73 @@ extern "C" int mgpu_lookup_terms(mgpu_ctx_t *c, const mgpu_term_lookup_t *lookup
     if (c->pend && c->pend->active) return fail(MGPU_E_ARG, "a batch is in flight on this context");
     if (n > 65535) return fail(MGPU_E_LIMIT, "more than 65535 lookups per call (one grid row each)");
     HIPCHK(hipSetDevice(c->device));
-    // job table + term blob
-    std::vector<TermJob> jobs((size_t)n);
-    std::vector<uint32_t> blob;
-    uint32_t max_words = 0;
+    // job table (sorted by dictionary: the filter kernel walks a dictionary once for all of its terms) + term blob
+    std::vector<uint32_t> order((size_t)n);
     for (int i = 0; i < n; i++) {
         const mgpu_term_lookup_t &l = lookups[i];
         if (!l.dict || !l.chars || l.len < 1 || l.len > MGPU_MAX_TERM_LEN) return fail(MGPU_E_ARG, "term of 0 or more than MGPU_MAX_TERM_LEN characters, or no dictionary");
         if (l.dict->device != c->device) return fail(MGPU_E_ARG, "dictionary lives on another device");
-        TermJob &j = jobs[(size_t)i];
+        order[(size_t)i] = (uint32_t)i;
+    }
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return (uintptr_t)lookups[a].dict < (uintptr_t)lookups[b].dict; });
+    std::vector<TermJob> jobs((size_t)n);
+    std::vector<TermDict> dicts;
+    std::vector<uint32_t> blob;
+    uint32_t max_words = 0;
+    for (int x = 0; x < n; x++) {
+        const uint32_t i = order[(size_t)x];
+        const mgpu_term_lookup_t &l = lookups[i];
+        TermJob &j = jobs[(size_t)x];
         j.chars = l.dict->chars; j.off = l.dict->off; j.wid = l.dict->wid; j.nwords = l.dict->nwords;
-        j.term_off = (uint32_t)blob.size(); j.tlen = l.len; j.prefix = l.prefix ? 1 : 0; j.maxdist = mg_lev_maxdist(l.len); j.pad = 0;
+        j.term_off = (uint32_t)blob.size(); j.tlen = l.len; j.prefix = l.prefix ? 1 : 0; j.maxdist = mg_lev_maxdist(l.len);
+        j.tsig = mg_lev_sig(l.chars, l.len); j.lookup = i; j.pad = 0;
         blob.insert(blob.end(), l.chars, l.chars + l.len);
+        if (dicts.empty() || dicts.back().sig != l.dict->sig) {
+            TermDict td; td.sig = l.dict->sig; td.nwords = l.dict->nwords; td.job_lo = (uint32_t)x; td.job_hi = (uint32_t)x; td.pad = 0;
+            dicts.push_back(td);
+        }
+        dicts.back().job_hi = (uint32_t)x + 1;
         max_words = std::max(max_words, j.nwords);
     }
-    const size_t jobs_b = (jobs.size() * sizeof(TermJob) + 255) & ~(size_t)255, blob_b = (blob.size() * 4 + 255) & ~(size_t)255;
-    if (c->lk_in_cap < jobs_b + blob_b) {
+    if (dicts.size() > 65535) return fail(MGPU_E_LIMIT, "more than 65535 dictionaries per call (one grid row each)");
+    const size_t jobs_b = (jobs.size() * sizeof(TermJob) + 255) & ~(size_t)255, dicts_b = (dicts.size() * sizeof(TermDict) + 255) & ~(size_t)255,
+                 blob_b = (blob.size() * 4 + 255) & ~(size_t)255;
+    if (c->lk_in_cap < jobs_b + dicts_b + blob_b) {
         if (c->lk_in) { (void)hipFree(c->lk_in); c->lk_in = nullptr; c->lk_in_cap = 0; }
-        const size_t cap = std::max<size_t>(jobs_b + blob_b, 1u << 20);
+        const size_t cap = std::max<size_t>(jobs_b + dicts_b + blob_b, 1u << 20);
         HIPCHK(hipMalloc((void **)&c->lk_in, cap));
         c->lk_in_cap = cap;
     }
     if (!c->lk_count) HIPCHK(hipMalloc((void **)&c->lk_count, 256));
     if (!c->lk_hits) { HIPCHK(hipMalloc((void **)&c->lk_hits, (size_t)(1u << 20) * 12)); c->lk_hits_cap = 1u << 20; }
+    if (!c->lk_cand) { HIPCHK(hipMalloc((void **)&c->lk_cand, (size_t)(1u << 22) * 8)); c->lk_cand_cap = 1u << 22; }
     hipStream_t st = c->stream;
     HIPCHK(hipMemcpyAsync(c->lk_in, jobs.data(), jobs.size() * sizeof(TermJob), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(c->lk_in + jobs_b, blob.data(), blob.size() * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->lk_in + jobs_b, dicts.data(), dicts.size() * sizeof(TermDict), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->lk_in + jobs_b + dicts_b, blob.data(), blob.size() * 4, hipMemcpyHostToDevice, st));
     uint32_t total = 0;
-    for (int attempt = 0; attempt < 2; attempt++) {
-        HIPCHK(hipMemsetAsync(c->lk_count, 0, 4, st));
-        mgk_term_scan(st, (const TermJob *)c->lk_in, (uint32_t)n, max_words, (const uint32_t *)(c->lk_in + jobs_b), c->lk_hits, c->lk_count, c->lk_hits_cap);
-        HIPCHK(hipMemcpyAsync(&total, c->lk_count, 4, hipMemcpyDeviceToHost, st));
+    for (int attempt = 0; attempt < 3; attempt++) {
+        uint32_t counts[2] = {0, 0};
+        HIPCHK(hipMemsetAsync(c->lk_count, 0, 8, st));
+        mgk_term_scan(st, (const TermJob *)c->lk_in, (const TermDict *)(c->lk_in + jobs_b), (uint32_t)dicts.size(), max_words,
+                      (const uint32_t *)(c->lk_in + jobs_b + dicts_b), c->lk_cand, c->lk_cand_cap, c->lk_hits, c->lk_count, c->lk_hits_cap);
+        HIPCHK(hipMemcpyAsync(counts, c->lk_count, 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         HIPCHK(hipGetLastError());
-        if (total <= c->lk_hits_cap) break;
-        if (attempt == 1) return fail(MGPU_E_HIP, "term scan hit count changed between two runs");
-        // the list was too short: the counter says how long it has to be
-        (void)hipFree(c->lk_hits); c->lk_hits = nullptr; c->lk_hits_cap = 0;
-        HIPCHK(hipMalloc((void **)&c->lk_hits, (size_t)total * 12));
-        c->lk_hits_cap = total;
+        total = counts[0];
+        if (counts[1] <= c->lk_cand_cap && total <= c->lk_hits_cap) break;
+        if (attempt == 2) return fail(MGPU_E_HIP, "term scan counts changed between runs");
+        // a list was too short: its counter says how long it has to be
+        if (counts[1] > c->lk_cand_cap) {
+            (void)hipFree(c->lk_cand); c->lk_cand = nullptr; c->lk_cand_cap = 0;
+            HIPCHK(hipMalloc((void **)&c->lk_cand, (size_t)counts[1] * 8));
+            c->lk_cand_cap = counts[1];
+        }
+        if (total > c->lk_hits_cap) {
+            (void)hipFree(c->lk_hits); c->lk_hits = nullptr; c->lk_hits_cap = 0;
+            HIPCHK(hipMalloc((void **)&c->lk_hits, (size_t)total * 12));
+            c->lk_hits_cap = total;
+        }
     }
     if (total) {
         mgpu_term_hit_t *h = (mgpu_term_hit_t *)malloc((size_t)total * sizeof(mgpu_term_hit_t));

@@ -2389,43 +2389,93 @@ __global__ void k_clock_cal(unsigned long long *out) {
     out[0] = w1 - w0; out[1] = clock64() - c0;
 }
 // ------------------------------------------------------------------ f-1: term lookup
-// dtrie_lookup_term's typo walk (dtrie.c:710-791) as a scan: one lane per dictionary word, scored on its own with the
-// walk's row arithmetic (mg_lev.h).  blockIdx.y = lookup, blockIdx.x = 256-word chunk of its dictionary (chunks past the
-// dictionary's end leave at once).  Matches are appended to one hit list with one atomic per wave; `count` keeps
-// counting past `cap`, so the host learns the size it needs.
-__global__ __launch_bounds__(MG_BLOCK) void k_term_scan(const TermJob *jobs, const uint32_t *term_chars,
-                                                        uint32_t *hits, uint32_t *count, uint32_t cap) {
-    __shared__ uint32_t s_term[MGPU_MAX_TERM_LEN + 1];
-    const TermJob *jp = &jobs[blockIdx.y];
-    const uint32_t nwords = jp->nwords;
+// dtrie_lookup_term's typo walk (dtrie.c:710-791) as a scan in two steps.
+// k_term_filter: blockIdx.y = dictionary, blockIdx.x = 256-word chunk of it; every lane holds ONE word's 4-byte
+// signature (mg_lev.h: character classes + length) and tests it against every term of the call that reads this
+// dictionary (term signatures staged in LDS, read as broadcasts): ~10 instructions per (term, word) pair instead of the
+// walk's several hundred.  The pairs that pass -- a necessary condition, about 1 in 100 -- go to a candidate list with
+// one atomic per wave.
+// k_term_eval: one lane per candidate scores the word with the walk's own row arithmetic (mg_lev_word) and appends the
+// matches {lookup, wid, distance} to the hit list.  Both counters keep counting past their caps, so the host learns the
+// sizes it needs.
+#define TF_TERMS 256
+#define TF_WBUF 512                                  // candidates a wave collects in LDS before it takes a range of the global list
+__global__ __launch_bounds__(MG_BLOCK) void k_term_filter(const TermJob *jobs, const TermDict *dicts, uint2 *cand, uint32_t *count, uint32_t cap) {
+    __shared__ uint2 s_t[TF_TERMS];                  // {tsig, maxdist | prefix << 8}
+    // One counter for the whole list, bumped by every wave that found something, serialises the chip on one address
+    // (measured: 6 ms per call, as slow as walking every word).  Each wave therefore collects in a buffer of its own --
+    // filled by its own lanes at ballot ranks, read back by the same wave: no barrier -- and takes a range of the list only when the
+    // buffer fills up and once at the end.
+    __shared__ uint2 s_buf[MG_BLOCK / 64][TF_WBUF];
+    const TermDict *dp = &dicts[blockIdx.y];
+    const uint32_t nwords = dp->nwords, job_lo = dp->job_lo, job_hi = dp->job_hi;
     if (blockIdx.x * MG_BLOCK >= nwords) return;
-    const uint32_t *chars = jp->chars, *off = jp->off, *wids = jp->wid;
-    const uint32_t term_off = jp->term_off;
-    int tlen = jp->tlen; const int prefix = jp->prefix, k = jp->maxdist;
-    if (tlen > MGPU_MAX_TERM_LEN) tlen = MGPU_MAX_TERM_LEN;          // the host refuses longer terms; never index past s_term
-    for (int i = threadIdx.x; i < tlen; i += MG_BLOCK) s_term[i] = term_chars[term_off + i];
-    __syncthreads();
     const uint32_t w = blockIdx.x * MG_BLOCK + threadIdx.x;
-    uint32_t dist = MG_LEV_NOMATCH, wid = 0;
-    if (w < nwords) {
-        const uint32_t o0 = off[w], o1 = off[w + 1];
-        // the walk ends by itself a few characters past the term's length; the bounds only keep the loop finite and
-        // inside the array on a damaged offset table (mgpu_dict_create checks the table)
-        int wlen = o1 > o0 ? (int)(o1 - o0) : 0;
-        if (wlen > 4096) wlen = 4096;
-        if (wlen > 0) dist = mg_lev_word((const uint32_t *)s_term, tlen, k, prefix, chars + o0, wlen);
-        wid = wids[w];
+    const bool valid = w < nwords;
+    const uint32_t wsig = valid ? dp->sig[w] : 0u;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint2 *buf = s_buf[wv];
+    uint32_t n = 0;                                  // entries in buf: the same value in every lane of the wave (ballots)
+    auto flush = [&]() {
+        uint32_t at = 0;
+        if (lane == 0) at = atomicAdd(count, n);
+        at = __shfl(at, 0, 64);
+        for (uint32_t x = lane; x < n; x += 64) if (at + x < cap) cand[at + x] = buf[x];
+    };
+    for (uint32_t j0 = job_lo; j0 < job_hi; j0 += TF_TERMS) {
+        const uint32_t nt = job_hi - j0 < TF_TERMS ? job_hi - j0 : TF_TERMS;
+        __syncthreads();
+        if (threadIdx.x < nt) {
+            const TermJob *jp = &jobs[j0 + threadIdx.x];
+            s_t[threadIdx.x] = make_uint2(jp->tsig, (uint32_t)jp->maxdist | ((uint32_t)jp->prefix << 8));
+        }
+        __syncthreads();
+        for (uint32_t i = 0; i < nt; i++) {
+            const uint2 t = s_t[i];
+            const bool pass = valid & mg_lev_sig_pass(t.x, (int)(t.y & 0xFF), (int)(t.y >> 8), wsig);
+            const u64 m = __ballot(pass);
+            if (!m) continue;
+            const uint32_t add = (uint32_t)__popcll(m);
+            if (n + add > TF_WBUF) { flush(); n = 0; }
+            if (pass) buf[n + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = make_uint2(j0 + i, w);
+            n += add;
+        }
     }
-    const bool hit = dist != MG_LEV_NOMATCH;
-    const u64 m = __ballot(hit);
-    if (!m) return;
-    const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
-    uint32_t at = 0;
-    if (lane == leader) at = atomicAdd(count, (uint32_t)__popcll(m));
-    at = __shfl(at, leader, 64);
-    if (hit) {
-        const uint32_t idx = at + (uint32_t)__popcll(m & ((1ull << lane) - 1));
-        if (idx < cap) { hits[3 * (size_t)idx] = blockIdx.y; hits[3 * (size_t)idx + 1] = wid; hits[3 * (size_t)idx + 2] = dist; }
+    if (n) flush();
+}
+__global__ __launch_bounds__(MG_BLOCK) void k_term_eval(const TermJob *jobs, const uint32_t *term_chars, const uint2 *cand, const uint32_t *cand_count,
+                                                        uint32_t cand_cap, uint32_t *hits, uint32_t *count, uint32_t cap) {
+    uint32_t n = *cand_count;
+    if (n > cand_cap) n = cand_cap;                 // the host runs the call again with a longer list
+    const int lane = threadIdx.x & 63;
+    for (uint32_t base = blockIdx.x * MG_BLOCK; base < n; base += gridDim.x * MG_BLOCK) {
+        const uint32_t x = base + threadIdx.x;
+        uint32_t dist = MG_LEV_NOMATCH, wid = 0, lookup = 0;
+        if (x < n) {
+            const uint2 cd = cand[x];
+            const TermJob *jp = &jobs[cd.x];
+            const uint32_t *off = jp->off;
+            const uint32_t o0 = off[cd.y], o1 = off[cd.y + 1];
+            // the walk ends by itself a few characters past the term's length; the bounds only keep the loop finite and
+            // inside the array on a damaged offset table (mgpu_dict_create checks the table)
+            int wlen = o1 > o0 ? (int)(o1 - o0) : 0;
+            if (wlen > 4096) wlen = 4096;
+            int tlen = jp->tlen;
+            if (tlen > MGPU_MAX_TERM_LEN) tlen = MGPU_MAX_TERM_LEN;
+            if (wlen > 0) dist = mg_lev_word(term_chars + jp->term_off, tlen, jp->maxdist, jp->prefix, jp->chars + o0, wlen);
+            wid = jp->wid[cd.y]; lookup = jp->lookup;
+        }
+        const bool hit = dist != MG_LEV_NOMATCH;
+        const u64 m = __ballot(hit);
+        if (!m) continue;
+        const int leader = __ffsll((long long)m) - 1;
+        uint32_t at = 0;
+        if (lane == leader) at = atomicAdd(count, (uint32_t)__popcll(m));
+        at = __shfl(at, leader, 64);
+        if (hit) {
+            const uint32_t idx = at + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+            if (idx < cap) { hits[3 * (size_t)idx] = lookup; hits[3 * (size_t)idx + 1] = wid; hits[3 * (size_t)idx + 2] = dist; }
+        }
     }
 }
 
@@ -2456,10 +2506,12 @@ int mgk_debug_phases(int on, unsigned long long *out16) {
     if (hipMemcpyToSymbol(HIP_SYMBOL(mg_dbg_on), &on, sizeof(int)) != hipSuccess) return -1;
     return 0;
 }
-void mgk_term_scan(hipStream_t st, const TermJob *jobs, uint32_t njobs, uint32_t max_words, const uint32_t *term_chars,
-                   uint32_t *hits, uint32_t *count, uint32_t cap) {
-    if (!njobs || !max_words) return;
-    hipLaunchKernelGGL(k_term_scan, dim3((max_words + MG_BLOCK - 1) / MG_BLOCK, njobs), dim3(MG_BLOCK), 0, st, jobs, term_chars, hits, count, cap);
+// counts[0] = hits, counts[1] = candidates (both zeroed by the caller)
+void mgk_term_scan(hipStream_t st, const TermJob *jobs, const TermDict *dicts, uint32_t ndicts, uint32_t max_words, const uint32_t *term_chars,
+                   uint2 *cand, uint32_t cand_cap, uint32_t *hits, uint32_t *counts, uint32_t cap) {
+    if (!ndicts || !max_words) return;
+    hipLaunchKernelGGL(k_term_filter, dim3((max_words + MG_BLOCK - 1) / MG_BLOCK, ndicts), dim3(MG_BLOCK), 0, st, jobs, dicts, cand, counts + 1, cand_cap);
+    hipLaunchKernelGGL(k_term_eval, dim3(1024), dim3(MG_BLOCK), 0, st, jobs, term_chars, (const uint2 *)cand, (const uint32_t *)(counts + 1), cand_cap, hits, counts, cap);
 }
 void mgk_scatter(hipStream_t st, const ScatterItem *items, uint32_t nitems) {
     if (!nitems) return;

@@ -202,5 +202,11 @@ struct TermJob {
     uint32_t nwords;
     uint32_t term_off;                   // the term's code points in the term blob
     int32_t tlen, prefix, maxdist;
-    uint32_t pad;
+    uint32_t tsig;                       // mg_lev_sig of the term
+    uint32_t lookup, pad;                // the caller's index of this lookup (the job table is sorted by dictionary)
+};
+// one dictionary of a lookup call and the run of jobs (sorted by dictionary) that read it
+struct TermDict {
+    const uint32_t *sig;                 // mg_lev_sig per word
+    uint32_t nwords, job_lo, job_hi, pad;
 };

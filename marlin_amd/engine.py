@@ -285,6 +285,20 @@ class GpuEngine:
             raise GpuError("msq_pipeline_run_resolved: %d %s" % (rc, self.lib.msq_pipeline_error(pipe).decode()))
         return hits.value, self.lib.msq_pipeline_plan_ms(pipe)
 
+    def run_pipeline_queries(self, pqs, batch, first, count, nthreads=None, warm=False):
+        """the native serving loop from the queries themselves: step i = the WHOLE of lookup_terms for queries
+        [(first + i) % nb * batch, + batch) -- dictionary lookups with the typo walks on the device (mgpu_lookup_terms on
+        the step's own context), exact descents on the host, process_termresult -- then execute + form_result, several
+        batches in flight.  Returns (summed totalHits, host ms in the dictionary half, host ms building plans)."""
+        pipe = self._pipeline(nthreads)
+        nq = len(pqs) // batch * batch
+        qarr = (C.POINTER(ffi.Query) * nq)(*[p.q for p in pqs[:nq]])
+        hits = C.c_long(0)
+        rc = self.lib.msq_pipeline_run_queries(pipe, self._marr, self.index.num_shards, qarr, nq, batch, first, count, 1 if warm else 0, C.byref(hits))
+        if rc:
+            raise GpuError("msq_pipeline_run_queries: %d %s" % (rc, self.lib.msq_pipeline_error(pipe).decode()))
+        return hits.value, self.lib.msq_pipeline_lookup_ms(pipe), self.lib.msq_pipeline_plan_ms(pipe)
+
     def free_prepared(self, prep):
         self.lib.msq_prepared_free(prep[0])
 

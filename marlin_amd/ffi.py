@@ -288,6 +288,8 @@ def load():
         "msq_pipeline_warm_resolved": (ci, [vp, C.POINTER(vp), ci]),
         "msq_pipeline_run_resolved": (ci, [vp, C.POINTER(vp), ci, ci, ci, C.POINTER(C.c_long)]),
         "msq_pipeline_plan_ms": (cd, [vp]),
+        "msq_pipeline_lookup_ms": (cd, [vp]),
+        "msq_pipeline_run_queries": (ci, [vp, C.POINTER(vp), ci, C.POINTER(C.POINTER(Query)), ci, ci, ci, ci, ci, C.POINTER(C.c_long)]),
         "msq_pipeline_set_gather": (ci, [vp, vp, ci, ci, ci, ci, ci]),
         "mgpu_comm_unique_id": (ci, [vp]),
         "mgpu_comm_create": (ci, [ci, vp, ci, ci, ci, C.c_size_t, C.POINTER(vp)]),

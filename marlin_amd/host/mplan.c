@@ -483,8 +483,8 @@ static void *resolve_worker(void *arg) {
 /* dtrie_lookup_term for every term and dtrie_lookup_exact for every word of every (query, shard) pair.  ctx != NULL: the
  * typo walks (dtrie.c:763-791) run on the device, ONE mgpu_lookup_terms call for the whole set (row f-1; ctx must be idle
  * and on the mirrors' device); the exact descents stay on the host (msq_plan_threads threads). */
-int msq_resolve_batch(mgpu_ctx_t *ctx, mmirror_t *const *mirrors, int num_shards, const m_query_t *const *queries, int nq,
-                      msq_resolved_t **out) {
+static int resolve_batch_impl(mgpu_ctx_t *ctx, mmirror_t *const *mirrors, int num_shards, const m_query_t *const *queries, int nq,
+                              int nthreads, msq_resolved_t **out) {
     *out = NULL;
     if (nq < 0 || num_shards < 1) return MGPU_E_ARG;
     const int n = nq * num_shards;
@@ -505,6 +505,9 @@ int msq_resolve_batch(mgpu_ctx_t *ctx, mmirror_t *const *mirrors, int num_shards
     struct timespec ts0, ts1, ts2;
     clock_gettime(CLOCK_MONOTONIC, &ts0);
     size_t nl = 0, nhits_total = 0;
+    /* device lookups: run l (dv_off[l] .. dv_off[l + 1]) of dv_wid / dv_dist is the result of term slot dv_slot_of[l] */
+    uint32_t *dv_off = NULL, *dv_wid = NULL, *dv_slot_of = NULL; uint8_t *dv_dist = NULL; size_t dv_n = 0;
+    struct resolve_job jobs[64]; pthread_t th[64]; int nworkers = 0, spawned = 0;
     if (ctx && n) {
         /* every term that dtrie_lookup_term would walk the trie for (mode 2) becomes one device lookup */
         for (int i = 0; i < n; i++) {
@@ -515,6 +518,7 @@ int msq_resolve_batch(mgpu_ctx_t *ctx, mmirror_t *const *mirrors, int num_shards
         }
         mgpu_term_lookup_t *lk = malloc(sizeof(*lk) * (nl ? nl : 1));
         uint32_t *slot = malloc(sizeof(uint32_t) * (nl ? nl : 1));          /* lookup -> index into tr[] */
+        dv_slot_of = malloc(sizeof(uint32_t) * (nl ? nl : 1));
         nl = 0;
         for (int i = 0; i < n; i++) {
             const m_query_t *q = queries[i / num_shards];
@@ -528,50 +532,94 @@ int msq_resolve_batch(mgpu_ctx_t *ctx, mmirror_t *const *mirrors, int num_shards
                 nl++;
             }
         }
-        /* at most 65535 lookups per call */
+        /* The hits of the device ({lookup, wid, distance}, any order) become one (wid, distance) run per lookup: counted
+         * per lookup, placed, then each short run ordered by wid with the least distance kept (add_wordid_to_result,
+         * dtrie.c:633-640) -- no hash map and no malloc per term.  At most 65535 lookups per call. */
+        dv_off = calloc(nl + 2, sizeof(uint32_t));
+        if (!dv_off) rc = MGPU_E_LIMIT;
+        /* the host's share (exact descents, twid terms: every slot without `have`) runs in worker threads WHILE the
+         * device scores the typo walks */
+        if (!rc) {
+            nworkers = nthreads < 1 ? 1 : nthreads > 64 ? 64 : nthreads;
+            if (nworkers > n) nworkers = n;
+            for (int t = 0; t < nworkers; t++) {
+                jobs[t] = (struct resolve_job){ mirrors, num_shards, queries, tr, have, r->exact,
+                                                (int)((long)n * t / nworkers), (int)((long)n * (t + 1) / nworkers) };
+                if (pthread_create(&th[t], NULL, resolve_worker, &jobs[t])) { nworkers = t; rc = MGPU_E_LIMIT; break; }
+            }
+            spawned = 1;
+        }
         for (size_t lo = 0; lo < nl && !rc; lo += 65535) {
             const int cnt = (int)(nl - lo < 65535 ? nl - lo : 65535);
             mgpu_term_hit_t *hits = NULL; uint32_t nh = 0;
             rc = mgpu_lookup_terms(ctx, lk + lo, cnt, &hits, &nh);
             if (rc) break;
-            for (uint32_t h = 0; h < nh; h++) {
-                if (hits[h].lookup >= (uint32_t)cnt) { rc = MGPU_E_HIP; break; }
-                m_termresult_t *x = &tr[slot[lo + hits[h].lookup]];
-                /* add_wordid_to_result (dtrie.c:633-640): least distance */
-                if ((int)hits[h].dist < m_u32map_get(&x->wordids, hits[h].wid, 0xFF)) m_u32map_set(&x->wordids, hits[h].wid, (int32_t)hits[h].dist);
+            uint32_t *nw = realloc(dv_wid, sizeof(uint32_t) * (dv_n + nh + 1));
+            if (nw) dv_wid = nw;
+            uint8_t *nd = realloc(dv_dist, dv_n + nh + 1);
+            if (nd) dv_dist = nd;
+            if (!nw || !nd) { rc = MGPU_E_LIMIT; mgpu_term_hits_free(hits); break; }
+            uint32_t *o = dv_off + lo + 1;                       /* o[l] = end of lookup l's run, then its fill position */
+            for (uint32_t h = 0; h < nh && !rc; h++) { if (hits[h].lookup >= (uint32_t)cnt) rc = MGPU_E_HIP; else o[hits[h].lookup]++; }
+            if (rc) { mgpu_term_hits_free(hits); break; }
+            uint32_t at = (uint32_t)dv_n;
+            for (int l = 0; l < cnt; l++) { const uint32_t c2 = o[l]; o[l] = at; at += c2; }
+            for (uint32_t h = 0; h < nh; h++) { const uint32_t x = o[hits[h].lookup]++; dv_wid[x] = hits[h].wid; dv_dist[x] = (uint8_t)hits[h].dist; }
+            /* now o[l] = end of run l; its start is the end of run l - 1 (or the old dv_n) */
+            uint32_t w = (uint32_t)dv_n, b = (uint32_t)dv_n;
+            for (int l = 0; l < cnt; l++) {
+                const uint32_t e = o[l], w0 = w;
+                for (uint32_t x = b; x < e; x++) {               /* insertion into [w0, w), ordered by wid */
+                    const uint32_t wd = dv_wid[x]; const uint8_t ds = dv_dist[x];
+                    uint32_t y = w;
+                    while (y > w0 && dv_wid[y - 1] > wd) y--;
+                    if (y > w0 && dv_wid[y - 1] == wd) { if (ds < dv_dist[y - 1]) dv_dist[y - 1] = ds; continue; }
+                    for (uint32_t z = w; z > y; z--) { dv_wid[z] = dv_wid[z - 1]; dv_dist[z] = dv_dist[z - 1]; }
+                    dv_wid[y] = wd; dv_dist[y] = ds; w++;
+                }
+                b = e; o[l] = w;
             }
+            dv_n = w;
             nhits_total += nh;
             mgpu_term_hits_free(hits);
         }
+        /* dv_off[l + 1] holds the end of run l; entry 0 its start */
+        if (!rc) for (size_t l = 0; l < nl; l++) dv_slot_of[l] = slot[l];
         free(lk); free(slot);
     }
     clock_gettime(CLOCK_MONOTONIC, &ts1);
+    if (spawned) for (int t = 0; t < nworkers; t++) pthread_join(th[t], NULL);
     if (!rc && n) {
-        int nthreads = msq_plan_threads;
-        if (nthreads > n) nthreads = n;
-        if (nthreads < 1) nthreads = 1;
-        if (nthreads > 64) nthreads = 64;
-        struct resolve_job jobs[64];
-        pthread_t th[64];
-        for (int t = 0; t < nthreads; t++) {
-            jobs[t] = (struct resolve_job){ mirrors, num_shards, queries, tr, have, r->exact,
-                                            (int)((long)n * t / nthreads), (int)((long)n * (t + 1) / nthreads) };
+        if (!spawned) {
+            if (nthreads > n) nthreads = n;
+            if (nthreads < 1) nthreads = 1;
+            if (nthreads > 64) nthreads = 64;
+            for (int t = 0; t < nthreads; t++) {
+                jobs[t] = (struct resolve_job){ mirrors, num_shards, queries, tr, have, r->exact,
+                                                (int)((long)n * t / nthreads), (int)((long)n * (t + 1) / nthreads) };
+            }
+            if (nthreads == 1) resolve_worker(&jobs[0]);
+            else {
+                for (int t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, resolve_worker, &jobs[t]);
+                for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+            }
         }
-        if (nthreads == 1) resolve_worker(&jobs[0]);
-        else {
-            for (int t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, resolve_worker, &jobs[t]);
-            for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
-        }
-        /* flatten */
-        size_t tot = 0;
+        /* flatten: host results from their maps, device results from their runs (lookups were made in slot order) */
+        size_t tot = dv_n;
         for (size_t k = 0; k < (size_t)n * M_MAX_QTERMS; k++) tot += tr[k].wordids.n;
         if (tot >= 0xFFFFFFFFull) rc = MGPU_E_LIMIT;
         else {
             r->wid = malloc(sizeof(uint32_t) * (tot ? tot : 1)); r->dist = malloc(tot ? tot : 1);
-            size_t at = 0;
+            size_t at = 0, l = 0;
             for (size_t k = 0; k < (size_t)n * M_MAX_QTERMS; k++) {
                 r->t_off[k] = (uint32_t)at;
                 r->twid[k] = tr[k].twid;
+                if (l < nl && dv_slot_of && dv_slot_of[l] == k) {
+                    const uint32_t a = dv_off[l], b = dv_off[l + 1];
+                    memcpy(r->wid + at, dv_wid + a, sizeof(uint32_t) * (size_t)(b - a)); memcpy(r->dist + at, dv_dist + a, (size_t)(b - a));
+                    at += b - a; l++;
+                    continue;
+                }
                 const m_u32map_t *mp = &tr[k].wordids;
                 for (uint32_t x = 0; x < mp->cap; x++) if (mp->keys[x]) { r->wid[at] = mp->keys[x]; r->dist[at] = (uint8_t)mp->vals[x]; at++; }
             }
@@ -586,9 +634,14 @@ int msq_resolve_batch(mgpu_ctx_t *ctx, mmirror_t *const *mirrors, int num_shards
     }
     for (size_t k = 0; k < (size_t)(n ? n : 1) * M_MAX_QTERMS; k++) if (tr[k].wordids.cap) m_termresult_free(&tr[k]);
     free(tr); free(have);
+    free(dv_off); free(dv_wid); free(dv_dist); free(dv_slot_of);
     if (rc) { msq_resolved_free(r); return rc; }
     *out = r;
     return 0;
+}
+int msq_resolve_batch(mgpu_ctx_t *ctx, mmirror_t *const *mirrors, int num_shards, const m_query_t *const *queries, int nq,
+                      msq_resolved_t **out) {
+    return resolve_batch_impl(ctx, mirrors, num_shards, queries, nq, msq_plan_threads, out);
 }
 
 /* ---- prepared batches: the plans of a resolved set, all in one arena */
@@ -827,6 +880,11 @@ struct msq_pipeline {
     /* the current run: prepared batches (preps), or resolved sets whose plans every step builds first (res) */
     const msq_prepared_t *const *preps; int nprep, first, count, every;
     const msq_resolved_t *const *res;
+    /* ... or raw queries (q_all: q_nb batches of q_batch queries): every step also does the dictionary half, with the
+     * typo walks on the step's own context (row f-1), before it builds its plans */
+    const m_query_t *const *q_all; int q_nb, q_batch, q_ns, q_threads; mmirror_t *const *q_mirrors;
+    msq_resolved_t *slot_res[128];        /* per context: the resolved set behind slot_pp (query runs) */
+    double lookup_ms[64];                 /* per thread: wall time of the dictionary half in the last run */
     msq_prepared_t *slot_pp[128];         /* per context: the plans of the batch it has in flight (resolved runs) */
     double plan_ms[64];                   /* per thread: wall time spent building plans in the last run */
     long hits[64]; int rc[64];
@@ -911,16 +969,27 @@ static int pipe_collect(msq_pipeline_t *p, int t, int ci, long step, mgpu_ctx_t 
  * (lookup_terms after the dictionary: process_termresult, squery.c:72-118) */
 static const msq_prepared_t *pipe_batch(msq_pipeline_t *p, int t, int ci, int i, int *rc) {
     *rc = 0;
-    if (!p->res) return p->preps[(p->first + i) % p->nprep];
-    const double t0 = pipe_now();
+    if (!p->res && !p->q_all) return p->preps[(p->first + i) % p->nprep];
     if (!p->slot_pp[ci] && !(p->slot_pp[ci] = msq_prepared_new())) { *rc = MGPU_E_LIMIT; return NULL; }
-    *rc = msq_plan_resolved(p->res[(p->first + i) % p->nprep], 0, p->slot_pp[ci]);
+    const msq_resolved_t *r;
+    if (p->q_all) {
+        /* the context is idle here: its previous batch was collected before the slot came round again */
+        const double tl = pipe_now();
+        msq_resolved_free(p->slot_res[ci]); p->slot_res[ci] = NULL;
+        *rc = resolve_batch_impl(p->ctx[ci], p->q_mirrors, p->q_ns, p->q_all + (size_t)((p->first + i) % p->q_nb) * (size_t)p->q_batch,
+                                 p->q_batch, p->q_threads > 0 ? p->q_threads : 1, &p->slot_res[ci]);
+        p->lookup_ms[t] += pipe_now() - tl;
+        if (*rc) return NULL;
+        r = p->slot_res[ci];
+    } else r = p->res[(p->first + i) % p->nprep];
+    const double t0 = pipe_now();
+    *rc = msq_plan_resolved(r, 0, p->slot_pp[ci]);
     p->plan_ms[t] += pipe_now() - t0;
     return *rc ? NULL : p->slot_pp[ci];
 }
 
 static void pipe_steps(msq_pipeline_t *p, int t) {
-    p->hits[t] = 0; p->rc[t] = 0; p->plan_ms[t] = 0;
+    p->hits[t] = 0; p->rc[t] = 0; p->plan_ms[t] = 0; p->lookup_ms[t] = 0;
     mgpu_ctx_t *cx[2] = { p->ctx[2 * t], (2 * t + 1 < p->nctx) ? p->ctx[2 * t + 1] : NULL };
     const int ncx = cx[1] ? 2 : 1;
     if (p->every) {
@@ -1006,7 +1075,7 @@ int msq_pipeline_create(mgpu_ctx_t *const *ctxs, int nctx, msq_pipeline_t **out)
 
 static int pipe_dispatch(msq_pipeline_t *p, const msq_prepared_t *const *preps, const msq_resolved_t *const *res, int nprep,
                          int first, int count, int every, long *hits_out) {
-    if (!p || (!preps && !res) || nprep < 1 || count < 0) return MGPU_E_ARG;
+    if (!p || (!preps && !res && !p->q_all) || nprep < 1 || count < 0) return MGPU_E_ARG;
     pthread_mutex_lock(&p->mu);
     p->preps = preps; p->res = res; p->nprep = nprep; p->first = first; p->count = count; p->every = every;
     p->err[0] = 0;
@@ -1047,6 +1116,26 @@ int msq_pipeline_run_resolved(msq_pipeline_t *p, const msq_resolved_t *const *re
 }
 int msq_pipeline_warm_resolved(msq_pipeline_t *p, const msq_resolved_t *const *res, int nres) {
     return pipe_dispatch(p, NULL, res, nres, 0, nres, 1, NULL);
+}
+/* The same loop from the queries themselves: step i takes queries [(first + i) % nb * batch, + batch) through the WHOLE of
+ * lookup_terms (squery.c:144-167) -- dictionary lookups with the typo walks on the step's own context (mgpu_lookup_terms),
+ * exact descents on the host, then process_termresult -- and then submits it; nq = nb * batch queries, mirrors[s] for
+ * s < num_shards on the contexts' device.  The arrays must stay alive until the run returns. */
+int msq_pipeline_run_queries(msq_pipeline_t *p, mmirror_t *const *mirrors, int num_shards, const m_query_t *const *queries, int nq,
+                             int batch, int first, int count, int warm, long *hits_out) {
+    if (!p || !mirrors || !queries || batch < 1 || nq < batch || num_shards < 1) return MGPU_E_ARG;
+    p->q_all = queries; p->q_nb = nq / batch; p->q_batch = batch; p->q_ns = num_shards; p->q_mirrors = mirrors;
+    /* helper threads of a step's dictionary half: the plan-thread budget shared out among the pipeline's threads */
+    p->q_threads = msq_plan_threads / (p->nthreads > 0 ? p->nthreads : 1);
+    if (p->q_threads < 1) p->q_threads = 1;
+    const int rc = warm ? pipe_dispatch(p, NULL, NULL, p->q_nb, 0, p->q_nb, 1, NULL) : pipe_dispatch(p, NULL, NULL, p->q_nb, first, count, 0, hits_out);
+    p->q_all = NULL;
+    return rc;
+}
+double msq_pipeline_lookup_ms(const msq_pipeline_t *p) {
+    double t = 0;
+    if (p) for (int i = 0; i < p->nthreads; i++) t += p->lookup_ms[i];
+    return t;
 }
 /* host milliseconds the last run's threads spent building plans, summed over the threads */
 double msq_pipeline_plan_ms(const msq_pipeline_t *p) {
@@ -1093,6 +1182,7 @@ void msq_pipeline_destroy(msq_pipeline_t *p) {
     for (int t = 0; t < p->nthreads; t++) pthread_join(p->th[t], NULL);
     pthread_mutex_destroy(&p->mu); pthread_cond_destroy(&p->go); pthread_cond_destroy(&p->done);
     for (int i = 0; i < 128; i++) msq_prepared_free(p->slot_pp[i]);
+    for (int i = 0; i < 128; i++) msq_resolved_free(p->slot_res[i]);
     for (int i = 0; i < 128; i++) { mgpu_host_free(p->g_send[i]); mgpu_host_free(p->g_recv[i]); }
     pthread_mutex_destroy(&p->g_mu); pthread_cond_destroy(&p->g_cv);
     free(p->trace);

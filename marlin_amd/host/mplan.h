@@ -122,6 +122,12 @@ int  msq_pipeline_run(msq_pipeline_t *p, const msq_prepared_t *const *preps, int
 int  msq_pipeline_warm_resolved(msq_pipeline_t *p, const msq_resolved_t *const *res, int nres);
 int  msq_pipeline_run_resolved(msq_pipeline_t *p, const msq_resolved_t *const *res, int nres, int first, int count, long *hits_out);
 double msq_pipeline_plan_ms(const msq_pipeline_t *p);
+/* ... and with the dictionary lookups inside it too: step i = lookup_terms for `batch` queries x num_shards shards (typo
+ * walks on the step's context: mgpu_lookup_terms; exact descents on the host) + plans + submit / collect + form_result.
+ * warm != 0: every context takes every batch once (first / count ignored). */
+int  msq_pipeline_run_queries(msq_pipeline_t *p, mmirror_t *const *mirrors, int num_shards, const m_query_t *const *queries, int nq,
+                              int batch, int first, int count, int warm, long *hits_out);
+double msq_pipeline_lookup_ms(const msq_pipeline_t *p);
 /* several GPUs: every batch of the loop ends with ONE RCCL all-gather of its result slots, issued from the pipeline's
  * threads in step order; the rank merges queries rank, rank + world, ... of each batch (mplan.c) */
 int  msq_pipeline_set_gather(msq_pipeline_t *p, mgpu_comm_t *comm, int pairs, int k, int num_facets, int fmax, int num_aggs);

@@ -22,7 +22,7 @@ int lev_check(const uint32_t *wchars, const int *wlen, int nwords, const uint32_
     uint32_t *chars, *off, *wid, n;
     if (mdict_export_words(d, &chars, &off, &wid, &n)) return -1;
     if (n != mdict_word_count(d)) { printf("export holds %u of %u words\n", n, mdict_word_count(d)); return -2; }
-    int bad = 0; long matches = 0;
+    int bad = 0; long matches = 0, pairs = 0, passed = 0;
     at = 0;
     for (int t = 0; t < nterms; t++) {
         m_term_t term; memset(&term, 0, sizeof(term));
@@ -35,8 +35,15 @@ int lev_check(const uint32_t *wchars, const int *wlen, int nwords, const uint32_
         std::map<uint32_t, int> want, got;
         for (uint32_t k = 0; k < tr.wordids.cap; k++) if (tr.wordids.keys[k]) want[tr.wordids.keys[k]] = tr.wordids.vals[k];
         const int k = mg_lev_maxdist(tlen[t]);
+        // as the device does it: the signature filter first (k_term_filter), the walk only for the words it lets through
+        // (k_term_eval) -- a match the filter dropped would show up as a missing word below
+        const uint32_t tsig = mg_lev_sig(term.word.chars, tlen[t]);
         for (uint32_t w = 0; w < n; w++) {
-            const uint32_t dist = mg_lev_word(term.word.chars, tlen[t], k, tprefix[t], chars + off[w], (int)(off[w + 1] - off[w]));
+            const int wl = (int)(off[w + 1] - off[w]);
+            pairs++;
+            if (!mg_lev_sig_pass(tsig, k, tprefix[t], mg_lev_sig(chars + off[w], wl))) continue;
+            passed++;
+            const uint32_t dist = mg_lev_word(term.word.chars, tlen[t], k, tprefix[t], chars + off[w], wl);
             if (dist != MG_LEV_NOMATCH) got[wid[w]] = (int)dist;
         }
         matches += (long)want.size();
@@ -53,6 +60,7 @@ int lev_check(const uint32_t *wchars, const int *wlen, int nwords, const uint32_
     free(chars); free(off); free(wid);
     mdict_free(d);
     if (matches_out) *matches_out = matches;
+    if (getenv("LEV_CHECK_STATS")) printf("signature filter: %ld of %ld (term, word) pairs pass, %ld matches\n", passed, pairs, matches);
     return bad;
 }
 }

@@ -159,3 +159,45 @@ def test_scan_equals_trie_walk_on_a_zipf_vocabulary():
         assert n > 200
     finally:
         eng.close(); ix.close()
+
+
+def test_serving_loop_with_the_lookups_inside():
+    """msq_pipeline_run_queries: every step resolves its own queries (typo walks on the step's context, while other
+    batches are in flight on the others), builds plans, executes, merges -- the hit sums equal those of the loop that
+    is handed host-resolved term sets, over several passes and with more steps than batches"""
+    lib = ffi.load()
+    V, S = 20000, 9
+    shards = [lib.msynth_zipf(60000, V, 500, S, s, 2) for s in range(2)]
+    ix = Index.from_shards({}, shards, ["str"], ["num", "price"], ["flag"], ["cat", "hc"])
+    eng = GpuEngine(ix, num_ctx=4)
+    try:
+        rng = random.Random(11)
+        buf = C.create_string_buffer(16)
+
+        def word(r):
+            lib.msynth_zipf_word(V, S, r, buf)
+            return buf.value.decode()
+        qs = []
+        for _ in range(48):
+            ws = []
+            for _ in range(2):
+                w = word(rng.randrange(0, 40))
+                p = rng.randrange(1, len(w))
+                ws.append(w[:p] + rng.choice("abcdefghij") + w[p + 1:])
+            qs.append({"q": " ".join(ws + [word(rng.randrange(0, 64))[:3]]), "fullScan": True, "rankBy": {"num": "desc"}, "maxFacetResults": 5})
+        pqs = [ix.query(q) for q in qs]
+        B = 8
+        ress = [eng.resolve(pqs[b * B:(b + 1) * B]) for b in range(len(pqs) // B)]     # host trie walk
+        eng.warm_pipeline_resolved(ress, 4)
+        want, _ = eng.run_pipeline_resolved(ress, 0, 15, 4)
+        assert want > 0
+        for _ in range(2):
+            got, lk_ms, _ = eng.run_pipeline_queries(pqs, B, 0, 15, 4)
+            assert got == want and lk_ms > 0
+        want2, _ = eng.run_pipeline_resolved(ress, 3, 4, 4)
+        got2, _, _ = eng.run_pipeline_queries(pqs, B, 3, 4, 4)
+        assert got2 == want2
+        for r in ress:
+            eng.free_resolved(r)
+    finally:
+        eng.close(); ix.close()

@@ -8,7 +8,7 @@ mkdir -p $out
 export TMPDIR=/tmp
 timeout -k 10 400 python3 bench.py > $out/bench_plain.json 2> $out/bench_plain.err
 tail -c 3000 $out/bench_plain.json
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_if1 -o kt -- python3 bench.py --no-cpu --no-latency --inflight 1 --steps 1 --warmup 1 --sub 30 > $out/bench_if1.json 2> $out/kt_if1.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_if1 -o kt -- python3 bench.py --no-cpu --no-latency --inflight 1 --steps 1 --warmup 1 --sub 32 > $out/bench_if1.json 2> $out/kt_if1.err
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_def -o kt -- python3 bench.py --no-cpu --no-latency > $out/bench_def_profiled.json 2> $out/kt_def.err
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o pmc -- python3 bench.py --no-cpu --no-latency --inflight 1 --steps 1 --warmup 0 --sub 3 > $out/pmc_fetch.json 2> $out/pmc_fetch.err
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o pmc -- python3 bench.py --no-cpu --no-latency --inflight 1 --steps 1 --warmup 0 --sub 3 > $out/pmc_write.json 2> $out/pmc_write.err
