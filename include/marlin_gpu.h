@@ -95,6 +95,33 @@ void mgpu_shard_destroy(mgpu_shard_t *s);
 /* bytes of HBM held by the mirror */
 uint64_t mgpu_shard_bytes(const mgpu_shard_t *s);
 
+/* ---------------------------------------------------------------- mirror maintenance (row f-2) ------------------
+ * A committed bulk write (si_write_end, sindex.c:184-254: the write cache's mbmaps saved with mbmap_save, mbmap.c:183-251;
+ * one docid2data blob per new document, sindex.c:273-326; the new num_dbi keys, sindex.c:528-535) appends documents:
+ * docids above the old maximum, which every posting they touch gains at its end, and possibly postings, words and facet
+ * values the shard did not have.  mgpu_shard_apply_delta brings the mirror up to date from exactly that -- the new
+ * documents' blobs and, per posting, the docids ADDED -- instead of a rebuild: the sparse posting array is re-laid on the
+ * device (old run + new docids per posting, k_merge_postings) and its window index recomputed (k_build_winidx), dense rows
+ * take their new bits in place (k_scatter), records / docwords / positions / columns / facet ordinals of the new documents
+ * are appended into the headroom the mirror was built with (MGPU_MIRROR_HEADROOM, default 12.5 % + 4096 documents).
+ * MGPU_E_LIMIT = no room left (nothing was changed): rebuild the mirror with mgpu_shard_create.  The caller makes sure no
+ * batch that names this shard is in flight during the call.  Deleted or replaced documents are not a delta: rebuild. */
+typedef struct mgpu_shard_delta {
+    uint32_t max_docid;                 /* after the write; the new documents are old max_docid + 1 .. max_docid */
+    uint32_t num_postings;              /* pids of the scheme after the write: 0..num_postings-1 */
+    const uint32_t *old_pid;            /* [num_postings] the posting's pid before the write (ascending), 0xFFFFFFFF = a new
+                                         * posting; NULL = the old pids keep their numbers and new postings follow them */
+    const uint64_t *post_off;           /* [num_postings + 1] CSR by (new) pid of the docids ADDED to each posting: all of */
+    const uint32_t *post_doc;           /* them new documents, ascending */
+    const uint64_t *dd_off;             /* [new documents + 1]: blob of new document i (docid old max + 1 + i) = */
+    const uint8_t  *dd;                 /* dd[dd_off[i], dd_off[i + 1]), reference layout as in mgpu_shard_desc_t */
+    uint64_t        np_n[MGPU_MAX_FIELDS];      /* num_dbi[i] after the write, complete (4 bytes per document and field: */
+    const uint32_t *np_doc[MGPU_MAX_FIELDS];    /* re-sent rather than merged) */
+} mgpu_shard_delta_t;
+int      mgpu_shard_apply_delta(mgpu_shard_t *s, const mgpu_shard_delta_t *delta);
+uint32_t mgpu_shard_max_docid(const mgpu_shard_t *s);
+uint32_t mgpu_shard_doc_capacity(const mgpu_shard_t *s);    /* largest max_docid a delta may bring */
+
 /* ---------------------------------------------------------------- plan -------------------- */
 /* filter program: postfix form of the reference's filter tree (filter_apply.c:207-227).
  * `docs` is the pre-filter docid_map, as in filter_apply's last argument. */

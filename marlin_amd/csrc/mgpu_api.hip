@@ -42,6 +42,10 @@ void mgk_row_op(hipStream_t st, const unsigned long long *a, const unsigned long
 void mgk_scatter_list(hipStream_t st, const uint32_t *src, uint64_t n, unsigned long long *dst);
 void mgk_fetch(hipStream_t st, void *dst, const void *src_pinned, size_t bytes);
 void mgk_facet_hash(hipStream_t st, const SelJob *jobs, const void *outs, const uint32_t *list, const uint32_t *count, uint32_t cap);
+void mgk_merge_postings(hipStream_t st, uint32_t num_postings, const uint32_t *old_pid, const int32_t *new_dense, const unsigned long long *new_off,
+                        const int32_t *old_dense, const unsigned long long *old_off, const uint32_t *old_doc,
+                        const unsigned long long *delta_off, const uint32_t *delta_doc, uint32_t *new_doc,
+                        const uint32_t *winbase, uint32_t nwin, uint32_t *post_win);
 void mgk_term_scan(hipStream_t st, const TermJob *jobs, const TermDict *dicts, uint32_t ndicts, uint32_t max_words, const uint32_t *term_chars,
                    uint2 *cand, uint32_t cand_cap, uint32_t *hits, uint32_t *counts, uint32_t cap);
 }
@@ -90,8 +94,39 @@ struct mgpu_shard {
     double avg_fv[MGPU_MAX_FIELDS];     // mean facet values per doc
     uint32_t n_dense;
     uint32_t rec_stride;
+    // ---- growth (mgpu_shard_apply_delta, row f-2): the arrays new documents append to are allocated with headroom
+    uint32_t cap_docs = 0;              // docids the per-document arrays and the bitmap rows have room for (N <= cap_docs)
+    uint64_t n_dw = 0, cap_dw = 0, n_pp = 0, cap_pp = 0;          // docword entries, decoded positions (and the pool copy behind the records)
+    uint64_t n_fa[MGPU_MAX_FIELDS] = {0}, cap_fa[MGPU_MAX_FIELDS] = {0};   // facet values per field
+    uint32_t cap_ord[MGPU_MAX_FIELDS] = {0};                      // ordinals per field (fa_ord2id)
+    uint32_t rec_hdr = 0, rec_FA = 0, rec_nnum_in = 0;            // the record layout, fixed when the mirror is built
+    uint64_t rec_pool_at = 0;                                     // u32 index in rec where the position pool copy starts
+    bool all_staged = false;
+    uint64_t n_sparse = 0;                                        // entries in post_doc
+    std::vector<uint32_t> fa_sorted_id[MGPU_MAX_FIELDS], fa_sorted_ord[MGPU_MAX_FIELDS];   // facet ids ascending -> their ordinals
 };
+// fraction of headroom a mirror is built with (MGPU_MIRROR_HEADROOM, default 0.125; 0 = none: every delta is refused)
+static double mirror_headroom() {
+    const char *e = getenv("MGPU_MIRROR_HEADROOM");               // read when a mirror is built
+    const double v = e ? atof(e) : 0.125;
+    return v < 0 ? 0.0 : v > 4 ? 4.0 : v;
+}
+static uint64_t with_headroom(uint64_t n, uint64_t slack) { const double h = mirror_headroom(); return h > 0 ? n + (uint64_t)((double)n * h) + slack : n; }
 
+// the same with room for `cap` elements (cap >= v.size()); the tail is zeroed
+template <typename T>
+static int upload_cap(mgpu_shard *s, const std::vector<T> &v, size_t cap, const T **out) {
+    if (cap < v.size()) cap = v.size();
+    size_t bytes = std::max<size_t>(cap, 1) * sizeof(T);
+    void *p = nullptr;
+    HIPCHK(hipMalloc(&p, bytes));
+    s->allocs.push_back(p);
+    s->bytes += bytes;
+    if (!v.empty()) HIPCHK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    if (cap > v.size()) HIPCHK(hipMemset((char *)p + v.size() * sizeof(T), 0, (cap - v.size()) * sizeof(T)));
+    *out = (const T *)p;
+    return MGPU_OK;
+}
 template <typename T>
 static int upload(mgpu_shard *s, const std::vector<T> &v, const T **out) {
     size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
@@ -182,6 +217,111 @@ extern "C" void mgpu_shard_destroy(mgpu_shard_t *s) {
 
 extern "C" uint64_t mgpu_shard_bytes(const mgpu_shard_t *s) { return s ? s->bytes : 0; }
 
+// ---- what the docid2data blobs of a run of documents decode to (sindex.c:273-326, 409-496).  Offsets are relative to
+// the run: document i of the run owns dw[dw_off[i] .. dw_off[i + 1]) and so on.
+struct DocRun {
+    std::vector<uint32_t> dw_off, pp_off;                  // [ndocs + 1]
+    std::vector<uint2> dw;                                 // {wid, info}
+    std::vector<uint32_t> pp;                              // decoded positions: (priority << 16) + position
+    std::vector<std::vector<double>> cols;                 // [num_numbers][ndocs]
+    std::vector<std::vector<uint32_t>> fa_off, fa_ids;     // [num_facets][ndocs + 1], facet ids
+};
+// blob of document i of the run = dd[dd_off[i], dd_off[i + 1])
+static int decode_docs(const uint8_t *dd, const uint64_t *dd_off, uint32_t ndocs, int nn, int nf, DocRun &R) {
+    R.dw_off.assign((size_t)ndocs + 1, 0); R.pp_off.assign((size_t)ndocs + 1, 0);
+    R.cols.assign(nn, std::vector<double>(ndocs, 0.0));
+    R.fa_off.assign(nf, std::vector<uint32_t>((size_t)ndocs + 1, 0));
+    R.fa_ids.assign(nf, std::vector<uint32_t>());
+    for (uint32_t i = 0; i < ndocs; i++) {
+        R.dw_off[i] = (uint32_t)R.dw.size(); R.pp_off[i] = (uint32_t)R.pp.size();
+        for (int f = 0; f < nf; f++) R.fa_off[f][i] = (uint32_t)R.fa_ids[f].size();
+        const uint8_t *blob = dd + dd_off[i];
+        const uint64_t bsz = dd_off[i + 1] - dd_off[i];
+        if (bsz < 4) continue;
+        uint32_t off; memcpy(&off, blob, 4);
+        for (int k = 0; k < nn; k++) memcpy(&R.cols[k][i], blob + 4 + (size_t)k * 8, 8);
+        const uint8_t *fpos = blob + 4 + (size_t)nn * 8;
+        for (int f = 0; f < nf; f++) {
+            uint32_t cnt; memcpy(&cnt, fpos, 4);
+            for (uint32_t j = 0; j < cnt; j++) { uint32_t id; memcpy(&id, fpos + 4 + (size_t)j * 4, 4); R.fa_ids[f].push_back(id); }
+            fpos += 4 + (size_t)cnt * 4;
+        }
+        if ((uint64_t)off + 2 > bsz) continue;
+        const uint8_t *wp = blob + off;
+        uint16_t numwid; memcpy(&numwid, wp, 2);
+        const uint32_t pool_base = (uint32_t)R.pp.size();
+        for (uint32_t w = 0; w < numwid; w++) {
+            uint32_t wid, info; memcpy(&wid, wp + 2 + (size_t)w * 8, 4); memcpy(&info, wp + 6 + (size_t)w * 8, 4);
+            if (info & 1u) { R.dw.push_back(make_uint2(wid, info)); continue; }
+            // fill_positions (docrank.c:21-45): freq, then {priority, count, vints, 0xFF} groups
+            const uint8_t *c = wp + (info >> 9);
+            int freq = *c++;
+            const uint32_t start = (uint32_t)R.pp.size() - pool_base;
+            uint32_t n = 0;
+            while (freq > 0) {
+                int priority = *c++; int count = *c++;
+                freq -= count;
+                while (count > 0) { int position; c = rd_vint(c, &position); R.pp.push_back(((uint32_t)priority << 16) + (uint32_t)position); n++; count--; }
+                c++;
+            }
+            if (n > 255 || start >= (1u << 23)) return fail(MGPU_E_LIMIT, "word frequency or document too large for the mirror");
+            R.dw.push_back(make_uint2(wid, (n << 1) | (start << 9)));
+        }
+    }
+    R.dw_off[ndocs] = (uint32_t)R.dw.size(); R.pp_off[ndocs] = (uint32_t)R.pp.size();
+    for (int f = 0; f < nf; f++) R.fa_off[f][ndocs] = (uint32_t)R.fa_ids[f].size();
+    return MGPU_OK;
+}
+// The records of a run of documents (layout: ShardDev::rec), document i of the run = docid first_doc + i.  base_dw / base_pp:
+// entries of the shard's docword / position arrays before the run.  fa_ords[f] = the run's facet values as ordinals.
+// rec: ndocs * stride / 4 words, zeroed; rlen: ndocs bytes.  Clears s->all_staged when a document's facet section is
+// not staged whole by the rank kernel.
+static void build_records(mgpu_shard *s, const DocRun &R, const std::vector<std::vector<uint32_t>> &fa_ords, uint32_t first_doc,
+                          uint64_t base_dw, uint64_t base_pp, uint32_t *rec, uint8_t *rlen) {
+    const uint32_t S = s->rec_stride, hdr = s->rec_hdr, FA = s->rec_FA, ws_c = (hdr + FA) / 8;
+    const int nnum_in = (int)s->rec_nnum_in, nf = (int)R.fa_off.size();
+    const uint32_t ndocs = (uint32_t)R.dw_off.size() - 1;
+    const bool pool_in = !getenv("MGPU_NO_POOLIN");                  // measurement switch, read when records are built
+    for (uint32_t i = 0; i < ndocs; i++) {
+        const uint32_t doc = first_doc + i;
+        uint32_t *r = rec + (size_t)i * (S / 4);
+        const uint32_t nwords = R.dw_off[i + 1] - R.dw_off[i];
+        uint32_t fb = 0;
+        for (int f = 0; f < nf; f++) fb += 4 + 4 * (R.fa_off[f][i + 1] - R.fa_off[f][i]);
+        fb = (fb + 7) & ~7u;
+        const bool facets_in = nf > 0 && fb <= FA;
+        if (!facets_in || fb > 4 * MG_PCAP) s->all_staged = false;
+        uint32_t nin = (S - 8 * ws_c) / 8;
+        if (nin > nwords) nin = nwords;
+        uint32_t used = 8 * (ws_c + nin);                     // bytes
+        r[0] = (nwords > 0xFFFF ? 0xFFFFu : nwords) | (nin << 16);
+        r[1] = (uint32_t)(s->rec_pool_at + base_pp + R.pp_off[i]);
+        r[2] = (uint32_t)(base_dw + R.dw_off[i] + nin);
+        r[3] = (uint32_t)nnum_in | ((facets_in ? 1u : 0u) << 8) | (ws_c << 16);
+        for (int k = 0; k < nnum_in; k++) memcpy(&r[4 + 2 * k], &R.cols[k][i], 8);
+        if (facets_in) {
+            uint32_t *fp = r + hdr / 4;
+            for (int f = 0; f < nf; f++) {
+                const uint32_t a = R.fa_off[f][i], b = R.fa_off[f][i + 1];
+                *fp++ = b - a;
+                for (uint32_t j = a; j < b; j++) *fp++ = fa_ords[f][j];
+            }
+        }
+        for (uint32_t j = 0; j < nin; j++) { r[2 * (ws_c + j)] = R.dw[R.dw_off[i] + j].x; r[2 * (ws_c + j) + 1] = R.dw[R.dw_off[i] + j].y; }
+        // the document's decoded positions right behind its docwords when everything fits: the rank kernel's
+        // position reads then land in the lines it has just fetched (the lanes that hold them do not take them
+        // for docword entries: the header's entry count says where the entries end)
+        const uint32_t npos = R.pp_off[i + 1] - R.pp_off[i];
+        if (pool_in && nin == nwords && npos > 0 && used + 4 * npos <= S) {
+            for (uint32_t j = 0; j < npos; j++) r[used / 4 + j] = R.pp[R.pp_off[i] + j];
+            r[1] = (uint32_t)((size_t)doc * (S / 4) + used / 4);
+            used += 4 * npos;
+        }
+        rlen[i] = (uint8_t)((used + 15) / 16);
+    }
+}
+
+static int set_num_order(mgpu_shard *s, int i, const uint32_t *doc, uint64_t n, const uint32_t **np_out, const uint64_t **grp_out);
 static int shard_create_impl(int device, const mgpu_shard_desc_t *d, mgpu_shard_t **out);
 extern "C" int mgpu_shard_create(int device, const mgpu_shard_desc_t *d, mgpu_shard_t **out) {
     if (!d || !out) return fail(MGPU_E_ARG, "null argument");
@@ -210,7 +350,9 @@ static int shard_create_impl(int device, const mgpu_shard_desc_t *d, mgpu_shard_
     memset(&s->dev, 0, sizeof(s->dev));
     ShardDev &sd = s->dev;
     const uint32_t N = d->max_docid + 1;
-    sd.N = N; sd.W = (N + 63) / 64; sd.Wp = (sd.W + 31) & ~31u;
+    s->cap_docs = (uint32_t)std::min<uint64_t>(with_headroom(N, 4096), 0xFFFFFFF0ull);
+    // W counts the words that hold documents; the row stride leaves room for cap_docs (rows grow in place)
+    sd.N = N; sd.W = (N + 63) / 64; sd.Wp = ((s->cap_docs + 63) / 64 + 31) & ~31u;
     sd.num_postings = d->num_postings;
     sd.num_facets = d->num_facets; sd.num_numbers = d->num_numbers;
     int rc = MGPU_OK;
@@ -231,6 +373,7 @@ static int shard_create_impl(int device, const mgpu_shard_desc_t *d, mgpu_shard_
             else sparse_doc.insert(sparse_doc.end(), d->post_doc + d->post_off[p], d->post_doc + d->post_off[p + 1]);
         }
         s->post_off[d->num_postings] = sparse_doc.size();
+        s->n_sparse = sparse_doc.size();
         if (sparse_doc.size() >= 0xFFFFFFFFull) { delete s; return fail(MGPU_E_LIMIT, "more than 2^32 sparse posting entries in one shard"); }
         for (uint32_t doc : sparse_doc) if (doc >= N) { delete s; return fail(MGPU_E_ARG, "posting docid beyond max_docid"); }
         // window index of the long sparse postings (see ShardDev::post_win)
@@ -275,72 +418,49 @@ static int shard_create_impl(int device, const mgpu_shard_desc_t *d, mgpu_shard_
         sd.dense = (const uint64_t *)p_rows; sd.post_dense = p_pd; sd.post_off = (const uint64_t *)p_off; sd.post_doc = p_doc;
     }
 
-    // ---- docid2data blobs -> docword CSR + position pool + facet ordinals + numeric columns
+    // ---- docid2data blobs -> docword CSR + position pool + facet ordinals + numeric columns + doc-major records
     {
+        DocRun R;
+        if ((rc = decode_docs(d->dd, d->dd_off + 1, N > 1 ? N - 1 : 0, d->num_numbers, d->num_facets, R))) { mgpu_shard_destroy(s); return rc; }
+        const uint32_t nd = N > 1 ? N - 1 : 0;
+        // per-docid arrays: entry 0 belongs to docid 0, which no document has
         std::vector<uint32_t> dw_off(N + 1, 0), pp_off(N + 1, 0);
-        std::vector<uint2> dw;
-        std::vector<uint32_t> pp;
-        std::vector<std::vector<double>> cols(d->num_numbers, std::vector<double>(N, 0.0));
-        std::vector<std::vector<uint32_t>> fa_off(d->num_facets, std::vector<uint32_t>(N + 1, 0));
-        std::vector<std::vector<uint32_t>> fa_ids(d->num_facets);
-        for (uint32_t doc = 1; doc < N; doc++) {
-            dw_off[doc] = (uint32_t)dw.size(); pp_off[doc] = (uint32_t)pp.size();
-            for (int f = 0; f < d->num_facets; f++) fa_off[f][doc] = (uint32_t)fa_ids[f].size();
-            const uint8_t *blob = d->dd + d->dd_off[doc];
-            const uint64_t bsz = d->dd_off[doc + 1] - d->dd_off[doc];
-            if (bsz < 4) continue;
-            uint32_t off; memcpy(&off, blob, 4);
-            for (int i = 0; i < d->num_numbers; i++) memcpy(&cols[i][doc], blob + 4 + (size_t)i * 8, 8);
-            const uint8_t *fpos = blob + 4 + (size_t)d->num_numbers * 8;
-            for (int f = 0; f < d->num_facets; f++) {
-                uint32_t cnt; memcpy(&cnt, fpos, 4);
-                for (uint32_t j = 0; j < cnt; j++) { uint32_t id; memcpy(&id, fpos + 4 + (size_t)j * 4, 4); fa_ids[f].push_back(id); }
-                fpos += 4 + (size_t)cnt * 4;
-            }
-            if ((uint64_t)off + 2 > bsz) continue;
-            const uint8_t *wp = blob + off;
-            uint16_t numwid; memcpy(&numwid, wp, 2);
-            const uint32_t pool_base = (uint32_t)pp.size();
-            for (uint32_t i = 0; i < numwid; i++) {
-                uint32_t wid, info; memcpy(&wid, wp + 2 + (size_t)i * 8, 4); memcpy(&info, wp + 6 + (size_t)i * 8, 4);
-                if (info & 1u) { dw.push_back(make_uint2(wid, info)); continue; }
-                // fill_positions (docrank.c:21-45): freq, then {priority, count, vints, 0xFF} groups
-                const uint8_t *c = wp + (info >> 9);
-                int freq = *c++;
-                const uint32_t start = (uint32_t)pp.size() - pool_base;
-                uint32_t n = 0;
-                while (freq > 0) {
-                    int priority = *c++; int count = *c++;
-                    freq -= count;
-                    while (count > 0) { int position; c = rd_vint(c, &position); pp.push_back(((uint32_t)priority << 16) + (uint32_t)position); n++; count--; }
-                    c++;
-                }
-                if (n > 255 || start >= (1u << 23)) { mgpu_shard_destroy(s); return fail(MGPU_E_LIMIT, "word frequency or document too large for the mirror"); }
-                dw.push_back(make_uint2(wid, (n << 1) | (start << 9)));
-            }
+        for (uint32_t i = 0; i <= nd; i++) { dw_off[1 + i] = R.dw_off[i]; pp_off[1 + i] = R.pp_off[i]; }
+        if (!nd) { dw_off[N] = 0; pp_off[N] = 0; }
+        s->avg_dw = N > 1 ? (double)R.dw.size() / (double)(N - 1) : 0.0;
+        s->n_dw = R.dw.size(); s->n_pp = R.pp.size();
+        s->cap_dw = with_headroom(s->n_dw, 65536); s->cap_pp = with_headroom(s->n_pp, 65536);
+        sd.dw_len = (uint32_t)R.dw.size(); sd.pp_len = (uint32_t)R.pp.size();
+        const size_t capN = (size_t)s->cap_docs + 1;
+        if ((rc = upload_cap(s, dw_off, capN, &sd.dw_off)) || (rc = upload_cap(s, R.dw, s->cap_dw, &sd.dw)) ||
+            (rc = upload_cap(s, pp_off, capN, &sd.pp_off)) || (rc = upload_cap(s, R.pp, s->cap_pp, &sd.pp))) { mgpu_shard_destroy(s); return rc; }
+        for (int i = 0; i < d->num_numbers; i++) {
+            std::vector<double> col(N, 0.0);
+            if (nd) memcpy(col.data() + 1, R.cols[i].data(), (size_t)nd * sizeof(double));
+            if ((rc = upload_cap(s, col, capN, &sd.num_col[i]))) { mgpu_shard_destroy(s); return rc; }
         }
-        dw_off[N] = (uint32_t)dw.size(); pp_off[N] = (uint32_t)pp.size();
-        dw_off[0] = 0; pp_off[0] = 0;
-        s->avg_dw = N > 1 ? (double)dw.size() / (double)(N - 1) : 0.0;
-        sd.dw_len = (uint32_t)dw.size(); sd.pp_len = (uint32_t)pp.size();
-        if ((rc = upload(s, dw_off, &sd.dw_off)) || (rc = upload(s, dw, &sd.dw)) ||
-            (rc = upload(s, pp_off, &sd.pp_off)) || (rc = upload(s, pp, &sd.pp))) { mgpu_shard_destroy(s); return rc; }
-        for (int i = 0; i < d->num_numbers; i++)
-            if ((rc = upload(s, cols[i], &sd.num_col[i]))) { mgpu_shard_destroy(s); return rc; }
         std::vector<std::vector<uint32_t>> fa_ords(d->num_facets);
         for (int f = 0; f < d->num_facets; f++) {
-            fa_off[f][N] = (uint32_t)fa_ids[f].size(); fa_off[f][0] = 0;
-            std::vector<uint32_t> uniq(fa_ids[f]);
+            std::vector<uint32_t> fa_off(N + 1, 0);
+            for (uint32_t i = 0; i <= nd; i++) fa_off[1 + i] = R.fa_off[f][i];
+            std::vector<uint32_t> uniq(R.fa_ids[f]);
             std::sort(uniq.begin(), uniq.end());
             uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
             std::vector<uint32_t> &ords = fa_ords[f];
-            ords.resize(fa_ids[f].size());
+            ords.resize(R.fa_ids[f].size());
             for (size_t i = 0; i < ords.size(); i++)
-                ords[i] = (uint32_t)(std::lower_bound(uniq.begin(), uniq.end(), fa_ids[f][i]) - uniq.begin());
+                ords[i] = (uint32_t)(std::lower_bound(uniq.begin(), uniq.end(), R.fa_ids[f][i]) - uniq.begin());
             sd.fa_nord[f] = (uint32_t)uniq.size();
             s->avg_fv[f] = N > 1 ? (double)ords.size() / (double)(N - 1) : 0.0;
-            if ((rc = upload(s, fa_off[f], &sd.fa_off[f])) || (rc = upload(s, ords, &sd.fa_ord[f])) ||
-                (rc = upload(s, uniq, &sd.fa_ord2id[f]))) { mgpu_shard_destroy(s); return rc; }
+            s->n_fa[f] = ords.size(); s->cap_fa[f] = with_headroom(ords.size(), 65536);
+            s->cap_ord[f] = (uint32_t)std::min<uint64_t>(with_headroom(uniq.size(), 4096), 0xFFFFFFF0ull);
+            // ordinals are handed out in ascending id order here; documents added later (mgpu_shard_apply_delta) append
+            // theirs, so the ascending list of ids with their ordinals is kept apart (facet recount: id -> posting)
+            s->fa_sorted_id[f] = uniq;
+            s->fa_sorted_ord[f].resize(uniq.size());
+            for (size_t i = 0; i < uniq.size(); i++) s->fa_sorted_ord[f][i] = (uint32_t)i;
+            if ((rc = upload_cap(s, fa_off, capN, &sd.fa_off[f])) || (rc = upload_cap(s, ords, s->cap_fa[f], &sd.fa_ord[f])) ||
+                (rc = upload_cap(s, uniq, s->cap_ord[f], &sd.fa_ord2id[f])) || (rc = upload(s, uniq, &sd.fa_sorted_id[f]))) { mgpu_shard_destroy(s); return rc; }
         }
         // ---- doc-major records.  The stages after the match formula visit an effectively random
         // 0.1-10 % of the documents; with column/CSR arrays every visit costs a cache line per array.
@@ -350,117 +470,310 @@ static int shard_create_impl(int device, const mgpu_shard_desc_t *d, mgpu_shard_
         {
             const int nnum_in = d->num_numbers <= 4 ? d->num_numbers : 0;
             const uint32_t hdr = 16 + 8 * (uint32_t)nnum_in;
-            auto facet_bytes = [&](uint32_t doc) {
+            auto facet_bytes = [&](uint32_t i) {
                 uint32_t b = 0;
-                for (int f = 0; f < d->num_facets; f++) b += 4 + 4 * (fa_off[f][doc + 1] - fa_off[f][doc]);
+                for (int f = 0; f < d->num_facets; f++) b += 4 + 4 * (R.fa_off[f][i + 1] - R.fa_off[f][i]);
                 return (b + 7) & ~7u;
             };
             // The facet area has ONE size per shard (what 90 % of the documents need, at most 64 B), so that the docword
             // entries of every record start at the same 8-byte slot `ws`: the rank kernel's lanes know their role without
             // reading a header.  A document whose facet section is larger keeps it in the per-field CSR (facets_in = 0).
             uint32_t FA = 0;
-            if (d->num_facets > 0 && N > 1) {
+            if (d->num_facets > 0 && nd) {
                 std::vector<uint32_t> fh(9, 0);                       // facet bytes in units of 8, 8 = "more than 56"
-                for (uint32_t doc = 1; doc < N; doc++) fh[std::min<uint32_t>(facet_bytes(doc) / 8, 8)]++;
+                for (uint32_t i = 0; i < nd; i++) fh[std::min<uint32_t>(facet_bytes(i) / 8, 8)]++;
                 uint32_t acc = 0, u = 8;
-                for (uint32_t c = 0; c <= 8; c++) { acc += fh[c]; if ((uint64_t)acc * 10 >= (uint64_t)(N - 1) * 9) { u = c; break; } }
+                for (uint32_t c = 0; c <= 8; c++) { acc += fh[c]; if ((uint64_t)acc * 10 >= (uint64_t)nd * 9) { u = c; break; } }
                 FA = std::min<uint32_t>(u, 8) * 8;
             }
             // stride: the smallest multiple of 128 B that holds 90 % of the documents whole (<= 512)
             std::vector<uint32_t> hist(5, 0);
-            for (uint32_t doc = 1; doc < N; doc++) {
-                uint32_t need = hdr + FA + 8 * (dw_off[doc + 1] - dw_off[doc]);
+            for (uint32_t i = 0; i < nd; i++) {
+                uint32_t need = hdr + FA + 8 * (R.dw_off[i + 1] - R.dw_off[i]);
                 uint32_t c = (need + 127) / 128; if (c > 4) c = 4;
                 hist[c]++;
             }
             uint32_t S = 512, acc = 0;
-            for (uint32_t c = 1; c <= 4; c++) { acc += hist[c]; if ((uint64_t)acc * 10 >= (uint64_t)(N - 1) * 9) { S = c * 128; break; } }
+            for (uint32_t c = 1; c <= 4; c++) { acc += hist[c]; if ((uint64_t)acc * 10 >= (uint64_t)nd * 9) { S = c * 128; break; } }
             if (hdr + FA + 8 > S) { FA = 0; }                          // degenerate schema: no facet area
-            const uint32_t ws_c = (hdr + FA) / 8;
-            const uint64_t rec_u32 = (uint64_t)N * (S / 4);
-            std::vector<uint32_t> rec((size_t)N * (S / 4) + pp.size(), 0);
-            if (!pp.empty()) memcpy(rec.data() + rec_u32, pp.data(), pp.size() * sizeof(uint32_t));
-            // bytes of each record that hold anything, in 16-byte units (the lanes beyond it load nothing); only when
-            // docids fit 24 bits, because the kernel carries the length in the top byte of its docid word
+            s->rec_hdr = hdr; s->rec_FA = FA; s->rec_nnum_in = (uint32_t)nnum_in; s->rec_stride = S;
+            // Word 1 of a record is the u32 index of the document's positions in ONE array: the records (with room for
+            // cap_docs of them), then a copy of the shard's position pool.  Positions that fit behind a document's
+            // docwords are placed there (index into the record itself), the others are found in the copy; the kernel
+            // adds the index to one base pointer either way.
+            s->rec_pool_at = (uint64_t)s->cap_docs * (S / 4);
+            if (s->rec_pool_at + s->cap_pp >= 0xFFFFFFFFull) { mgpu_shard_destroy(s); return fail(MGPU_E_LIMIT, "records + positions beyond 2^32 words in one shard"); }
+            std::vector<uint32_t> rec((size_t)N * (S / 4), 0);
             std::vector<uint8_t> rlen(N, 0);
-            // (MGPU_NO_POOLIN / MGPU_NO_RECLEN: measurement switches, read when a mirror is built)
-            // Word 1 of a record is the u32 index of the document's positions in ONE array: the records, then a copy of
-            // the shard's position pool.  Positions that fit behind a document's docwords are placed there (index into the
-            // record itself), the others are found in the copy; the kernel adds the index to one base pointer either way.
-            if (rec_u32 + pp.size() >= 0xFFFFFFFFull) { mgpu_shard_destroy(s); return fail(MGPU_E_LIMIT, "records + positions beyond 2^32 words in one shard"); }
-            const bool pool_in = !getenv("MGPU_NO_POOLIN");
-            bool all_staged = d->num_facets > 0;
-            uint64_t n_pool_in = 0, n_full = 0;
-            for (uint32_t doc = 1; doc < N; doc++) {
-                uint32_t *r = rec.data() + (size_t)doc * (S / 4);
-                const uint32_t nwords = dw_off[doc + 1] - dw_off[doc];
-                const uint32_t fb = facet_bytes(doc);
-                const bool facets_in = d->num_facets > 0 && fb <= FA;
-                if (!facets_in || fb > 4 * MG_PCAP) all_staged = false;
-                uint32_t nin = (S - 8 * ws_c) / 8;
-                if (nin > nwords) nin = nwords;
-                uint32_t used = 8 * (ws_c + nin);                     // bytes
-                r[0] = (nwords > 0xFFFF ? 0xFFFFu : nwords) | (nin << 16);
-                r[1] = (uint32_t)(rec_u32 + pp_off[doc]);
-                r[2] = dw_off[doc] + nin;
-                r[3] = (uint32_t)nnum_in | ((facets_in ? 1u : 0u) << 8) | (ws_c << 16);
-                for (int i = 0; i < nnum_in; i++) memcpy(&r[4 + 2 * i], &cols[i][doc], 8);
-                if (facets_in) {
-                    uint32_t *fp = r + hdr / 4;
-                    for (int f = 0; f < d->num_facets; f++) {
-                        const uint32_t a = fa_off[f][doc], b = fa_off[f][doc + 1];
-                        *fp++ = b - a;
-                        for (uint32_t j = a; j < b; j++) *fp++ = fa_ords[f][j];
-                    }
-                }
-                for (uint32_t j = 0; j < nin; j++) { r[2 * (ws_c + j)] = dw[dw_off[doc] + j].x; r[2 * (ws_c + j) + 1] = dw[dw_off[doc] + j].y; }
-                // the document's decoded positions right behind its docwords when everything fits: the rank kernel's
-                // position reads then land in the lines it has just fetched (the lanes that hold them do not take them
-                // for docword entries: the header's entry count says where the entries end)
-                const uint32_t npos = pp_off[doc + 1] - pp_off[doc];
-                if (pool_in && nin == nwords && npos > 0 && used + 4 * npos <= S) {
-                    for (uint32_t j = 0; j < npos; j++) r[used / 4 + j] = pp[pp_off[doc] + j];
-                    r[1] = (uint32_t)((size_t)doc * (S / 4) + used / 4);
-                    used += 4 * npos;
-                    n_pool_in++;
-                }
-                n_full += nin == nwords;
-                rlen[doc] = (uint8_t)((used + 15) / 16);
+            s->all_staged = d->num_facets > 0;
+            build_records(s, R, fa_ords, 1, 0, 0, rec.data() + (S / 4), rlen.data() + (N > 1 ? 1 : 0));
+            {
+                void *p = nullptr;
+                const size_t words = (size_t)s->rec_pool_at + (size_t)s->cap_pp;
+                HIPCHK(hipMalloc(&p, std::max<size_t>(words, 1) * 4));
+                s->allocs.push_back(p); s->bytes += words * 4;
+                HIPCHK(hipMemset(p, 0, std::max<size_t>(words, 1) * 4));
+                if (!rec.empty()) HIPCHK(hipMemcpy(p, rec.data(), rec.size() * 4, hipMemcpyHostToDevice));
+                if (!R.pp.empty()) HIPCHK(hipMemcpy((uint32_t *)p + s->rec_pool_at, R.pp.data(), R.pp.size() * 4, hipMemcpyHostToDevice));
+                sd.rec = (const uint32_t *)p;
+                sd.rec_words = (uint32_t)words;
             }
-            if ((rc = upload(s, rec, &sd.rec))) { mgpu_shard_destroy(s); return rc; }
-            { const uint8_t *pl; if ((rc = upload(s, rlen, &pl))) { mgpu_shard_destroy(s); return rc; } sd.rec_len = pl; }
+            { const uint8_t *pl; if ((rc = upload_cap(s, rlen, (size_t)s->cap_docs + 1, &pl))) { mgpu_shard_destroy(s); return rc; } sd.rec_len = pl; }
             // Off unless MGPU_RECLEN is set: measured on the bench corpus the predicated loads change nothing (0.660 vs
             // 0.655 ms per batch: the kernel is bound by instruction issue and latency, not by bytes) while the length
             // gather adds a third of a fabric request per hit to the counters (profiles/README.md, round 3)
-            s->rec_len_ok = N <= (1u << 24) && getenv("MGPU_RECLEN") != nullptr;
-            sd.rec_ws = ws_c; sd.rec_words = (uint32_t)rec.size();
-            if (all_staged)
+            s->rec_len_ok = s->cap_docs <= (1u << 24) && getenv("MGPU_RECLEN") != nullptr;
+            sd.rec_ws = (hdr + FA) / 8;
+            if (s->all_staged)
                 for (int f = 0; f < d->num_facets; f++) {
                     bool single = true;
-                    for (uint32_t doc = 1; doc < N && single; doc++) single = fa_off[f][doc + 1] - fa_off[f][doc] <= 1;
+                    for (uint32_t i = 0; i < nd && single; i++) single = R.fa_off[f][i + 1] - R.fa_off[f][i] <= 1;
                     if (single) s->fac_single |= 1u << f;
                 }
             sd.rec_stride = S; sd.rec_nnum = (uint32_t)nnum_in;
-            s->rec_stride = S;
         }
     }
     // ---- num_dbi docids in key order
-    for (int i = 0; i < d->num_numbers; i++) {
-        s->np_n[i] = d->np_n[i];
-        std::vector<uint32_t> v(d->np_doc[i], d->np_doc[i] + d->np_n[i]);
-        if ((rc = upload(s, v, &sd.np_doc[i]))) { mgpu_shard_destroy(s); return rc; }
-        // what fast-rank mode needs to know about the field: which idnum2dbl groups exist, and whether a document has
-        // several values
-        std::vector<uint64_t> grp(((size_t)N / 1000 + 64) / 64, 0), seen(sd.W ? sd.W : 1, 0);
-        for (uint32_t doc : v) {
-            if (doc >= N) { mgpu_shard_destroy(s); return fail(MGPU_E_ARG, "num_dbi docid beyond max_docid"); }
-            grp[(doc / 1000) >> 6] |= 1ull << ((doc / 1000) & 63);
-            if ((seen[doc >> 6] >> (doc & 63)) & 1ull) s->np_multi |= 1u << i;
-            seen[doc >> 6] |= 1ull << (doc & 63);
-        }
-        if ((rc = upload(s, grp, &sd.grp_has[i]))) { mgpu_shard_destroy(s); return rc; }
-    }
+    for (int i = 0; i < d->num_numbers; i++)
+        if ((rc = set_num_order(s, i, d->np_doc[i], d->np_n[i], &sd.np_doc[i], &sd.grp_has[i]))) { mgpu_shard_destroy(s); return rc; }
     *out = s;
+    return MGPU_OK;
+}
+
+// ------------------------------------------------------------------ f-2: a committed bulk write as a delta
+// num_dbi of one field (the complete order: value descending, docid ascending) -> np_doc, grp_has, np_multi
+static int set_num_order(mgpu_shard *s, int i, const uint32_t *doc, uint64_t n, const uint32_t **np_out, const uint64_t **grp_out) {
+    ShardDev &sd = s->dev;
+    const uint32_t N = sd.N;
+    s->np_n[i] = n;
+    std::vector<uint32_t> v(doc, doc + n);
+    int rc;
+    if ((rc = upload(s, v, np_out))) return rc;
+    // what fast-rank mode needs to know about the field: which idnum2dbl groups exist, and whether a document has
+    // several values
+    std::vector<uint64_t> grp(((size_t)s->cap_docs / 1000 + 64) / 64 + 1, 0), seen(sd.W ? sd.W : 1, 0);
+    s->np_multi &= ~(1u << i);
+    for (uint32_t x : v) {
+        if (x >= N) return fail(MGPU_E_ARG, "num_dbi docid beyond max_docid");
+        grp[(x / 1000) >> 6] |= 1ull << ((x / 1000) & 63);
+        if ((seen[x >> 6] >> (x & 63)) & 1ull) s->np_multi |= 1u << i;
+        seen[x >> 6] |= 1ull << (x & 63);
+    }
+    return upload(s, grp, grp_out);
+}
+static void drop_alloc(mgpu_shard *s, const void *p, size_t bytes) {
+    if (!p) return;
+    for (size_t i = 0; i < s->allocs.size(); i++) if (s->allocs[i] == p) { s->allocs[i] = s->allocs.back(); s->allocs.pop_back(); break; }
+    (void)hipFree((void *)p);
+    s->bytes -= std::min<uint64_t>(s->bytes, bytes);
+}
+
+extern "C" uint32_t mgpu_shard_max_docid(const mgpu_shard_t *s) { return s ? s->dev.N - 1 : 0; }
+extern "C" uint32_t mgpu_shard_doc_capacity(const mgpu_shard_t *s) { return s ? s->cap_docs - 1 : 0; }
+
+extern "C" int mgpu_shard_apply_delta(mgpu_shard_t *s, const mgpu_shard_delta_t *d) {
+    if (!s || !d || !d->post_off || (d->num_postings && !d->post_doc && d->post_off[d->num_postings])) return fail(MGPU_E_ARG, "null argument");
+    ShardDev &sd = s->dev;
+    const uint32_t N0 = sd.N, N1 = d->max_docid + 1;
+    if (N1 < N0) return fail(MGPU_E_ARG, "a delta cannot take documents away");
+    if (N1 > s->cap_docs) return fail(MGPU_E_LIMIT, "the mirror has no room for that many more documents: rebuild it");
+    if (d->num_postings < sd.num_postings) return fail(MGPU_E_ARG, "a delta cannot take postings away");
+    const uint32_t nd = N1 - N0, P0 = sd.num_postings, P1 = d->num_postings;
+    if (nd && (!d->dd_off || !d->dd)) return fail(MGPU_E_ARG, "blobs of the new documents missing");
+    HIPCHK(hipSetDevice(s->device));
+    int rc;
+    // ---- 1. everything that can fail is prepared before the mirror is touched
+    // pid scheme: every old posting exactly once, in order
+    std::vector<uint32_t> old_pid(P1);
+    {
+        uint32_t next = 0;
+        for (uint32_t p = 0; p < P1; p++) {
+            const uint32_t op = d->old_pid ? d->old_pid[p] : (p < P0 ? p : 0xFFFFFFFFu);
+            if (op != 0xFFFFFFFFu) { if (op != next) return fail(MGPU_E_ARG, "old pids must appear once each, ascending"); next++; }
+            old_pid[p] = op;
+        }
+        if (next != P0) return fail(MGPU_E_ARG, "the delta's pid map does not cover the mirror's postings");
+        if (P1 && old_pid[0] != 0) return fail(MGPU_E_ARG, "pid 0 (all documents) must stay pid 0");
+    }
+    for (uint32_t p = 0; p < P1; p++) {
+        if (d->post_off[p + 1] < d->post_off[p]) return fail(MGPU_E_ARG, "delta posting offsets must ascend");
+        for (uint64_t i = d->post_off[p]; i < d->post_off[p + 1]; i++) {
+            const uint32_t x = d->post_doc[i];
+            if (x < N0 || x >= N1) return fail(MGPU_E_ARG, "a delta posting holds a docid that is not new");
+            if (i > d->post_off[p] && x <= d->post_doc[i - 1]) return fail(MGPU_E_ARG, "delta posting docids not ascending");
+        }
+    }
+    // the new documents
+    DocRun R;
+    if ((rc = decode_docs(d->dd, d->dd_off, nd, sd.num_numbers, sd.num_facets, R))) return rc;
+    if (s->n_dw + R.dw.size() > s->cap_dw || s->n_pp + R.pp.size() > s->cap_pp || s->n_dw + R.dw.size() >= 0xFFFFFFFFull)
+        return fail(MGPU_E_LIMIT, "the mirror has no room for the new documents' words: rebuild it");
+    // facet ids -> ordinals; ids the field has not seen get the next ordinals
+    std::vector<std::vector<uint32_t>> fa_ords(sd.num_facets), new_ids(sd.num_facets);
+    std::vector<std::vector<uint32_t>> sorted_id(sd.num_facets), sorted_ord(sd.num_facets);
+    for (int f = 0; f < sd.num_facets; f++) {
+        if (s->n_fa[f] + R.fa_ids[f].size() > s->cap_fa[f]) return fail(MGPU_E_LIMIT, "the mirror has no room for the new documents' facet values: rebuild it");
+        std::vector<uint32_t> fresh;
+        const std::vector<uint32_t> &sid = s->fa_sorted_id[f];
+        for (uint32_t id : R.fa_ids[f]) if (!std::binary_search(sid.begin(), sid.end(), id)) fresh.push_back(id);
+        std::sort(fresh.begin(), fresh.end());
+        fresh.erase(std::unique(fresh.begin(), fresh.end()), fresh.end());
+        if ((uint64_t)sd.fa_nord[f] + fresh.size() > s->cap_ord[f]) return fail(MGPU_E_LIMIT, "the mirror has no room for the new facet values: rebuild it");
+        new_ids[f] = fresh;                                               // ordinal of fresh[i] = fa_nord + i
+        // merged ascending id list with ordinals
+        sorted_id[f].reserve(sid.size() + fresh.size()); sorted_ord[f].reserve(sid.size() + fresh.size());
+        size_t a = 0, b = 0;
+        while (a < sid.size() || b < fresh.size()) {
+            if (b >= fresh.size() || (a < sid.size() && sid[a] < fresh[b])) { sorted_id[f].push_back(sid[a]); sorted_ord[f].push_back(s->fa_sorted_ord[f][a]); a++; }
+            else { sorted_id[f].push_back(fresh[b]); sorted_ord[f].push_back(sd.fa_nord[f] + (uint32_t)b); b++; }
+        }
+        fa_ords[f].resize(R.fa_ids[f].size());
+        for (size_t i = 0; i < fa_ords[f].size(); i++) {
+            const size_t at = (size_t)(std::lower_bound(sorted_id[f].begin(), sorted_id[f].end(), R.fa_ids[f][i]) - sorted_id[f].begin());
+            fa_ords[f][i] = sorted_ord[f][at];
+        }
+    }
+    const uint32_t S = s->rec_stride;
+    std::vector<uint32_t> rec((size_t)nd * (S / 4), 0);
+    std::vector<uint8_t> rlen(nd, 0);
+    bool staged = s->all_staged;
+    {
+        const bool keep = s->all_staged;
+        build_records(s, R, fa_ords, N0, s->n_dw, s->n_pp, rec.data(), rlen.data());
+        staged = s->all_staged; s->all_staged = keep;                     // committed below
+    }
+    // postings: dense rows keep their rows, everything else is a run of the new sparse array
+    std::vector<int32_t> new_dense(P1, -1);
+    std::vector<uint64_t> new_off((size_t)P1 + 1, 0);
+    std::vector<uint32_t> new_card(P1, 0), winbase(P1, 0xFFFFFFFFu);
+    const uint32_t W1 = (N1 + 63) / 64, nwin = (W1 + MG_FORMULA_WORDS - 1) / MG_FORMULA_WORDS;
+    uint64_t nsp = 0, nwi = 0;
+    std::vector<ScatterItem> items;
+    for (uint32_t p = 0; p < P1; p++) {
+        const uint32_t op = old_pid[p];
+        const uint64_t dn = d->post_off[p + 1] - d->post_off[p];
+        new_off[p] = nsp;
+        uint64_t n = dn;
+        if (op != 0xFFFFFFFFu) {
+            new_dense[p] = s->post_dense[op];
+            n += s->post_card[op];
+            if (new_dense[p] < 0) nsp += s->post_off[op + 1] - s->post_off[op];
+        }
+        new_card[p] = (uint32_t)std::min<uint64_t>(n, N1);
+        if (new_dense[p] < 0) {
+            nsp += dn;
+            const uint64_t len = nsp - new_off[p];
+            if (len > MG_SHORT_POSTING) { winbase[p] = (uint32_t)nwi; nwi += (uint64_t)nwin + 1; }
+        }
+    }
+    new_off[P1] = nsp;
+    if (nsp >= 0xFFFFFFFFull || nwi >= 0xFFFFFFFFull) return fail(MGPU_E_LIMIT, "more than 2^32 sparse posting entries or window entries in one shard");
+    // ---- 2. device work: the delta's docids, the merged sparse array and its window index, the dense rows' new bits
+    uint32_t *d_delta = nullptr, *d_newdoc = nullptr, *d_win = nullptr, *d_oldpid = nullptr, *d_winbase = nullptr;
+    u64 *d_deltaoff = nullptr, *d_newoff = nullptr; int32_t *d_newdense = nullptr; ScatterItem *d_items = nullptr;
+    auto cleanup_tmp = [&]() { if (d_delta) (void)hipFree(d_delta); if (d_deltaoff) (void)hipFree(d_deltaoff); if (d_oldpid) (void)hipFree(d_oldpid);
+                               if (d_winbase) (void)hipFree(d_winbase); if (d_items) (void)hipFree(d_items); };
+    auto bail = [&](hipError_t e) { cleanup_tmp(); if (d_newdoc) (void)hipFree(d_newdoc); if (d_win) (void)hipFree(d_win);
+                                     if (d_newoff) (void)hipFree(d_newoff); if (d_newdense) (void)hipFree(d_newdense);
+                                     return fail(MGPU_E_HIP, hipGetErrorString(e)); };
+    hipError_t e;
+    const uint64_t ndelta = d->post_off[P1];
+#define TRY(x) do { if ((e = (x)) != hipSuccess) return bail(e); } while (0)
+    TRY(hipMalloc((void **)&d_delta, std::max<uint64_t>(ndelta, 1) * 4));
+    TRY(hipMalloc((void **)&d_deltaoff, ((size_t)P1 + 1) * 8));
+    TRY(hipMalloc((void **)&d_oldpid, std::max<size_t>(P1, 1) * 4));
+    TRY(hipMalloc((void **)&d_winbase, std::max<size_t>(P1, 1) * 4));
+    TRY(hipMalloc((void **)&d_newdoc, std::max<uint64_t>(nsp, 1) * 4));
+    TRY(hipMalloc((void **)&d_win, std::max<uint64_t>(nwi, 1) * 4));
+    TRY(hipMalloc((void **)&d_newoff, ((size_t)P1 + 1) * 8));
+    TRY(hipMalloc((void **)&d_newdense, std::max<size_t>(P1, 1) * 4));
+    if (ndelta) TRY(hipMemcpy(d_delta, d->post_doc, ndelta * 4, hipMemcpyHostToDevice));
+    TRY(hipMemcpy(d_deltaoff, d->post_off, ((size_t)P1 + 1) * 8, hipMemcpyHostToDevice));
+    if (P1) {
+        TRY(hipMemcpy(d_oldpid, old_pid.data(), (size_t)P1 * 4, hipMemcpyHostToDevice));
+        TRY(hipMemcpy(d_winbase, winbase.data(), (size_t)P1 * 4, hipMemcpyHostToDevice));
+        TRY(hipMemcpy(d_newdense, new_dense.data(), (size_t)P1 * 4, hipMemcpyHostToDevice));
+    }
+    TRY(hipMemcpy(d_newoff, new_off.data(), ((size_t)P1 + 1) * 8, hipMemcpyHostToDevice));
+    for (uint32_t p = 0; p < P1; p++) {
+        if (new_dense[p] < 0) continue;
+        const uint64_t a = d->post_off[p], n = d->post_off[p + 1] - a;
+        for (uint64_t at = 0; at < n; at += MG_SCATTER_CHUNK) {
+            ScatterItem it; it.src = d_delta + a + at; it.dst = (uint64_t *)sd.dense + (size_t)new_dense[p] * sd.Wp;
+            it.n = (uint32_t)std::min<uint64_t>(n - at, MG_SCATTER_CHUNK); it.pad = 0;
+            items.push_back(it);
+        }
+    }
+    if (!items.empty()) {
+        TRY(hipMalloc((void **)&d_items, items.size() * sizeof(ScatterItem)));
+        TRY(hipMemcpy(d_items, items.data(), items.size() * sizeof(ScatterItem), hipMemcpyHostToDevice));
+    }
+    // the merged array is built next to the live one; the rows' new bits are the first change of the mirror itself
+    mgk_merge_postings(nullptr, P1, d_oldpid, d_newdense, (const unsigned long long *)d_newoff, sd.post_dense, (const unsigned long long *)sd.post_off, sd.post_doc,
+                       (const unsigned long long *)d_deltaoff, d_delta, d_newdoc, d_winbase, nwin, d_win);
+    TRY(hipStreamSynchronize(nullptr));
+    TRY(hipGetLastError());
+    if (!items.empty()) mgk_scatter(nullptr, d_items, (uint32_t)items.size());
+    TRY(hipStreamSynchronize(nullptr));
+    TRY(hipGetLastError());
+    // ---- 3. the appended tails of the per-document arrays
+    auto put = [&](const void *dst_base, size_t elem, size_t at, const void *src, size_t n) -> hipError_t {
+        if (!n) return hipSuccess;
+        return hipMemcpy((char *)dst_base + at * elem, src, n * elem, hipMemcpyHostToDevice);
+    };
+    {
+        std::vector<uint32_t> o(nd + 1);
+        for (uint32_t i = 0; i <= nd; i++) o[i] = (uint32_t)(s->n_dw + R.dw_off[i]);
+        TRY(put(sd.dw_off, 4, N0, o.data(), (size_t)nd + 1));
+        for (uint32_t i = 0; i <= nd; i++) o[i] = (uint32_t)(s->n_pp + R.pp_off[i]);
+        TRY(put(sd.pp_off, 4, N0, o.data(), (size_t)nd + 1));
+        TRY(put(sd.dw, sizeof(uint2), s->n_dw, R.dw.data(), R.dw.size()));
+        TRY(put(sd.pp, 4, s->n_pp, R.pp.data(), R.pp.size()));
+        TRY(put(sd.rec, 4, s->rec_pool_at + s->n_pp, R.pp.data(), R.pp.size()));
+        for (int i = 0; i < sd.num_numbers; i++) TRY(put(sd.num_col[i], 8, N0, R.cols[i].data(), nd));
+        for (int f = 0; f < sd.num_facets; f++) {
+            for (uint32_t i = 0; i <= nd; i++) o[i] = (uint32_t)(s->n_fa[f] + R.fa_off[f][i]);
+            TRY(put(sd.fa_off[f], 4, N0, o.data(), (size_t)nd + 1));
+            TRY(put(sd.fa_ord[f], 4, s->n_fa[f], fa_ords[f].data(), fa_ords[f].size()));
+            TRY(put(sd.fa_ord2id[f], 4, sd.fa_nord[f], new_ids[f].data(), new_ids[f].size()));
+        }
+        TRY(put(sd.rec, 4, (size_t)N0 * (S / 4), rec.data(), rec.size()));
+        TRY(put(sd.rec_len, 1, N0, rlen.data(), nd));
+    }
+#undef TRY
+    cleanup_tmp();
+    // ---- 4. commit: the new posting tables replace the old ones
+    drop_alloc(s, sd.post_doc, (size_t)std::max<uint64_t>(s->n_sparse, 1) * 4);
+    drop_alloc(s, sd.post_win, 0);
+    drop_alloc(s, sd.post_off, ((size_t)P0 + 1) * 8);
+    drop_alloc(s, sd.post_dense, (size_t)std::max<uint32_t>(P0, 1) * 4);
+    s->allocs.push_back(d_newdoc); s->allocs.push_back(d_win); s->allocs.push_back(d_newoff); s->allocs.push_back(d_newdense);
+    s->bytes += nsp * 4 + nwi * 4 + ((size_t)P1 + 1) * 8 + (size_t)P1 * 4;
+    sd.post_doc = d_newdoc; sd.post_win = d_win; sd.post_off = (const uint64_t *)d_newoff; sd.post_dense = d_newdense;
+    sd.num_postings = P1; sd.N = N1; sd.W = W1;
+    s->post_dense = new_dense; s->post_off = new_off; s->post_card = new_card; s->post_winbase = winbase; s->n_sparse = nsp;
+    s->n_dw += R.dw.size(); s->n_pp += R.pp.size();
+    sd.dw_len = (uint32_t)s->n_dw; sd.pp_len = (uint32_t)s->n_pp;
+    s->avg_dw = N1 > 1 ? (double)s->n_dw / (double)(N1 - 1) : 0.0;
+    if (!staged) { s->all_staged = false; s->fac_single = 0; }
+    for (int f = 0; f < sd.num_facets; f++) {
+        s->n_fa[f] += fa_ords[f].size();
+        sd.fa_nord[f] += (uint32_t)new_ids[f].size();
+        s->avg_fv[f] = N1 > 1 ? (double)s->n_fa[f] / (double)(N1 - 1) : 0.0;
+        for (uint32_t i = 0; i < nd; i++) if (R.fa_off[f][i + 1] - R.fa_off[f][i] > 1) s->fac_single &= ~(1u << f);
+        s->fa_sorted_id[f].swap(sorted_id[f]); s->fa_sorted_ord[f].swap(sorted_ord[f]);
+        const uint32_t *old = sd.fa_sorted_id[f];
+        if ((rc = upload(s, s->fa_sorted_id[f], &sd.fa_sorted_id[f]))) return rc;
+        drop_alloc(s, old, 0);
+    }
+    // num_dbi: the complete order again (4 bytes per document and field)
+    for (int i = 0; i < sd.num_numbers; i++) {
+        const uint32_t *old_np = sd.np_doc[i]; const uint64_t *old_grp = sd.grp_has[i];
+        const uint64_t old_n = s->np_n[i];
+        if (d->np_n[i] && !d->np_doc[i]) return fail(MGPU_E_ARG, "num_dbi order missing");
+        if ((rc = set_num_order(s, i, d->np_doc[i], d->np_n[i], &sd.np_doc[i], &sd.grp_has[i]))) return rc;
+        drop_alloc(s, old_np, (size_t)std::max<uint64_t>(old_n, 1) * 4); drop_alloc(s, old_grp, 0);
+    }
     return MGPU_OK;
 }
 

@@ -546,11 +546,11 @@ __global__ __launch_bounds__(MG_BLOCK) void k_facet_recount(const SqDev *sqs, co
     if (n == 0xFFFFFFFFu) return;                                             // selection unfinished: the host reports it
     __shared__ uint32_t red[MG_BLOCK / 64];
     const uint32_t f = j.field, nord = sp->sh.fa_nord[f], W = sp->sh.W, Wp = sp->sh.Wp;
-    const uint32_t *ord2id = sp->sh.fa_ord2id[f];
+    const uint32_t *ord2id = sp->sh.fa_sorted_id[f];      // ids ascending: an id's position = its posting's offset from the field's base pid
     const u64 *D = (const u64 *)sp->docid_map;
     for (uint32_t x = 0; x < n; x++) {
         const uint32_t id = (uint32_t)j.out_lo[x];
-        uint32_t lo = 0, hi = nord;                                           // the id's ordinal: ord2id is ascending
+        uint32_t lo = 0, hi = nord;                                           // the id's place among the field's ids
         while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (ord2id[mid] < id) lo = mid + 1; else hi = mid; }
         const uint32_t pid = sp->fac_pid_base[f] + lo;
         uint32_t c = 0;
@@ -2517,6 +2517,60 @@ void mgk_scatter(hipStream_t st, const ScatterItem *items, uint32_t nitems) {
     if (!nitems) return;
     uint32_t grid = nitems < 8192 ? nitems : 8192;
     hipLaunchKernelGGL(k_scatter, dim3(grid), dim3(MG_BLOCK), 0, st, items, nitems);
+}
+// ------------------------------------------------------------------ f-2: mirror maintenance
+// A committed bulk write (sindex.c:184-254: si_write_end stores the changed mbmaps, the new docdata blobs and num_dbi
+// entries) appends documents: every posting gains docids above the old maximum.  The mirror takes that as a delta
+// instead of being rebuilt (mgpu_shard_apply_delta): the sparse posting array is re-laid on the device -- every
+// posting's old run followed by its new docids (mbmap_save's effect on the stored containers, mbmap.c:183-251) -- and the
+// window index of the long postings is recomputed from the merged lists; dense rows take their new bits through k_scatter.
+// One wave per posting.
+__global__ __launch_bounds__(MG_BLOCK) void k_merge_postings(uint32_t num_postings, const uint32_t *old_pid, const int32_t *new_dense,
+                                                             const u64 *new_off, const int32_t *old_dense, const u64 *old_off, const uint32_t *old_doc,
+                                                             const u64 *delta_off, const uint32_t *delta_doc, uint32_t *new_doc) {
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t p = blockIdx.x * (MG_BLOCK / 64) + (threadIdx.x >> 6); p < num_postings; p += gridDim.x * (MG_BLOCK / 64)) {
+        if (new_dense[p] >= 0) continue;
+        uint32_t *dst = new_doc + new_off[p];
+        u64 n0 = 0;
+        const uint32_t op = old_pid[p];
+        if (op != 0xFFFFFFFFu && old_dense[op] < 0) {
+            const u64 a = old_off[op]; n0 = old_off[op + 1] - a;
+            for (u64 i = lane; i < n0; i += 64) dst[i] = old_doc[a + i];
+        }
+        const u64 a = delta_off[p], n1 = delta_off[p + 1] - a;
+        for (u64 i = lane; i < n1; i += 64) dst[n0 + i] = delta_doc[a + i];
+    }
+}
+// post_win[winbase[p] + j] = first element of posting p (relative to its start) whose docid is >= j * 64 * MG_FORMULA_WORDS,
+// j = 0 .. nwin (the last entry = the posting's length).  One wave per indexed posting, one lane per window.
+__global__ __launch_bounds__(MG_BLOCK) void k_build_winidx(uint32_t num_postings, const uint32_t *winbase, const u64 *off, const uint32_t *doc,
+                                                           uint32_t nwin, uint32_t *post_win) {
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t p = blockIdx.x * (MG_BLOCK / 64) + (threadIdx.x >> 6); p < num_postings; p += gridDim.x * (MG_BLOCK / 64)) {
+        const uint32_t wb = winbase[p];
+        if (wb == 0xFFFFFFFFu) continue;
+        const uint32_t *list = doc + off[p];
+        const uint32_t n = (uint32_t)(off[p + 1] - off[p]);
+        for (uint32_t j = lane; j <= nwin; j += 64) {
+            uint32_t lo = 0, hi = n;
+            if (j < nwin) {
+                const u64 lim = (u64)j * 64 * MG_FORMULA_WORDS;
+                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((u64)list[mid] < lim) lo = mid + 1; else hi = mid; }
+            } else lo = n;
+            post_win[wb + j] = lo;
+        }
+    }
+}
+void mgk_merge_postings(hipStream_t st, uint32_t num_postings, const uint32_t *old_pid, const int32_t *new_dense, const unsigned long long *new_off,
+                        const int32_t *old_dense, const unsigned long long *old_off, const uint32_t *old_doc,
+                        const unsigned long long *delta_off, const uint32_t *delta_doc, uint32_t *new_doc,
+                        const uint32_t *winbase, uint32_t nwin, uint32_t *post_win) {
+    if (!num_postings) return;
+    uint32_t g = (num_postings + MG_BLOCK / 64 - 1) / (MG_BLOCK / 64); if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(k_merge_postings, dim3(g), dim3(MG_BLOCK), 0, st, num_postings, old_pid, new_dense, (const u64 *)new_off, old_dense,
+                       (const u64 *)old_off, old_doc, (const u64 *)delta_off, delta_doc, new_doc);
+    hipLaunchKernelGGL(k_build_winidx, dim3(g), dim3(MG_BLOCK), 0, st, num_postings, winbase, (const u64 *)new_off, (const uint32_t *)new_doc, nwin, post_win);
 }
 // The batch's lowered plans, fetched from pinned host memory by the GPU itself (16 bytes per lane over PCIe) instead
 // of a hipMemcpyAsync: on this runtime an H2D copy enqueued behind kernels of other streams was seen to hold the calling

@@ -56,6 +56,7 @@ struct ShardDev {
     const uint32_t *fa_off[MGPU_MAX_FIELDS];    // [N + 1]
     const uint32_t *fa_ord[MGPU_MAX_FIELDS];    // dense ordinals
     const uint32_t *fa_ord2id[MGPU_MAX_FIELDS]; // ordinal -> facet id
+    const uint32_t *fa_sorted_id[MGPU_MAX_FIELDS]; // the field's facet ids ascending (position = offset of the id's posting from fac_pid_base)
     uint32_t fa_nord[MGPU_MAX_FIELDS];
     // numbers
     const double   *num_col[MGPU_MAX_FIELDS];   // [N]

@@ -120,6 +120,34 @@ class GpuEngine:
         self._pipe = None
         self._pipe_n = 0
 
+    # ---- row f-2: the index was written to
+    def apply_index(self, new_index):
+        """`new_index` holds the shards after an append-only bulk write (same documents first, same docids).  Every mirror
+        takes the difference as a delta (mmirror_apply_shard -> mgpu_shard_apply_delta: merged posting array and window
+        index rebuilt on the device, new documents appended into the mirror's headroom); a mirror without room left is
+        rebuilt.  No batch may be in flight.  Returns per shard "delta" or "rebuilt"."""
+        lib = self.lib
+        if len(new_index.shards) != len(self.mirrors):
+            raise GpuError("apply_index: shard count changed")
+        how = []
+        for i, s in enumerate(new_index.shards):
+            rc = lib.mmirror_apply_shard(self.mirrors[i], s)
+            if rc == 0:
+                how.append("delta")
+                continue
+            if rc not in (-3, -5):
+                raise GpuError("mmirror_apply_shard: %d %s" % (rc, lib.mgpu_last_error().decode()))
+            m = C.c_void_p()
+            rc2 = lib.mmirror_create(s, self.device, C.byref(m))
+            if rc2:
+                raise GpuError("mmirror_create: %d %s" % (rc2, lib.mgpu_last_error().decode()))
+            lib.mmirror_destroy(self.mirrors[i])
+            self.mirrors[i] = m
+            how.append("rebuilt")
+        self._marr = (C.c_void_p * len(self.mirrors))(*[m.value for m in self.mirrors])
+        self.index = new_index
+        return how
+
     # ---- several GPUs (DESIGN.md (e)): one process per GPU, the pipeline's batches end with an RCCL all-gather
     def comm_unique_id(self):
         """128 bytes rank 0 makes and every rank needs (hand them round with whatever the launcher has)"""

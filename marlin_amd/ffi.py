@@ -287,6 +287,9 @@ def load():
         "msq_plan_resolved": (ci, [vp, ci, vp]),
         "msq_pipeline_warm_resolved": (ci, [vp, C.POINTER(vp), ci]),
         "msq_pipeline_run_resolved": (ci, [vp, C.POINTER(vp), ci, ci, ci, C.POINTER(C.c_long)]),
+        "mmirror_apply_shard": (ci, [vp, vp]),
+        "mgpu_shard_max_docid": (C.c_uint32, [vp]),
+        "mgpu_shard_doc_capacity": (C.c_uint32, [vp]),
         "msq_pipeline_plan_ms": (cd, [vp]),
         "msq_pipeline_lookup_ms": (cd, [vp]),
         "msq_pipeline_run_queries": (ci, [vp, C.POINTER(vp), ci, C.POINTER(C.POINTER(Query)), ci, ci, ci, ci, ci, C.POINTER(C.c_long)]),

@@ -86,6 +86,102 @@ int mmirror_create(const mshard_t *s, int device, mmirror_t **out) {
     return 0;
 }
 
+/* first element of the ascending list [a, a + n) that is > lim */
+static uint64_t tail_from(const uint32_t *a, uint64_t n, uint32_t lim) {
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (a[mid] <= lim) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+/* Row f-2: the shard `snew` is what the mirror's shard became after a committed, append-only bulk write (the old
+ * documents keep their docids, words and top-level words their ids: sindex.c hands out docids and the dtrie word ids in
+ * insertion order).  The mirror is brought up to date from the difference -- per posting the docids above the old
+ * maximum, the new documents' blobs, the new num_dbi order -- with mgpu_shard_apply_delta instead of a rebuild; the
+ * dictionary mirror is re-exported only when words were added.  MGPU_E_LIMIT: the mirror's headroom is used up, nothing
+ * was changed, build a new mirror (mmirror_create).  MGPU_E_UNSUPPORTED: not an append (documents deleted). */
+int mmirror_apply_shard(mmirror_t *m, const mshard_t *snew) {
+    if (!m || !m->g || !snew) return MGPU_E_ARG;
+    const mshard_t *so = m->s;
+    if (so->has_used || snew->has_used) return MGPU_E_UNSUPPORTED;
+    if (snew->max_docid < so->max_docid || snew->word_count < so->word_count || snew->tword_count < so->tword_count ||
+        snew->num_facets != so->num_facets || snew->num_numbers != so->num_numbers || snew->num_bools != so->num_bools) return MGPU_E_UNSUPPORTED;
+    mmirror_t *nm = mmirror_scheme(snew);
+    if (!nm) return MGPU_E_LIMIT;
+    const uint32_t P1 = nm->num_postings, old_max = so->max_docid;
+    uint32_t *old_pid = malloc(sizeof(uint32_t) * (size_t)(P1 ? P1 : 1));
+    uint64_t *off = malloc(sizeof(uint64_t) * ((size_t)P1 + 1));
+    /* an upper bound of the delta's size: every list's tail */
+    uint64_t cap = snew->max_docid - old_max, at = 0;
+    int rc = 0;
+    if (!old_pid || !off) rc = MGPU_E_LIMIT;
+    uint32_t *doc = NULL;
+    for (int pass = 0; pass < 2 && !rc; pass++) {
+        /* pass 0 sizes, pass 1 fills */
+        if (pass == 1) { doc = malloc(sizeof(uint32_t) * (size_t)(cap ? cap : 1)); if (!doc) { rc = MGPU_E_LIMIT; break; } }
+        uint32_t p = 0;
+        at = 0;
+#define TAIL(list, n, oldp) do { const uint32_t *l_ = (list); const uint64_t n_ = (n), t_ = tail_from(l_, n_, old_max); \
+            off[p] = at; old_pid[p] = (oldp); if (pass == 1 && n_ > t_) memcpy(doc + at, l_ + t_, (n_ - t_) * sizeof(uint32_t)); at += n_ - t_; p++; } while (0)
+        off[p] = 0; old_pid[p] = 0;                                   /* pid 0: every docid */
+        if (pass == 1) for (uint32_t d = old_max + 1; d <= snew->max_docid; d++) doc[at + (d - old_max - 1)] = d;
+        at += snew->max_docid - old_max; p++;
+        for (uint32_t w = 1; w <= nm->W; w++)
+            TAIL(snew->wp_doc + snew->wp_off[w], snew->wp_off[w + 1] - snew->wp_off[w], w <= m->W ? w : 0xFFFFFFFFu);
+        for (uint32_t t = 1; t <= nm->T; t++)
+            TAIL(snew->tp_doc + snew->tp_off[t], snew->tp_off[t + 1] - snew->tp_off[t], t <= m->T ? m->W + t : 0xFFFFFFFFu);
+        for (int f = 0; f < snew->num_facets && !rc; f++) {
+            uint32_t j = 0;                                           /* walks the old field's ids */
+            for (uint32_t k = 0; k < snew->nfid[f]; k++) {
+                uint32_t op = 0xFFFFFFFFu;
+                if (j < so->nfid[f] && so->fid[f][j] == snew->fid[f][k]) op = m->fbase[f] + j++;
+                else if (j < so->nfid[f] && so->fid[f][j] < snew->fid[f][k]) { rc = MGPU_E_UNSUPPORTED; break; }   /* an old facet value is gone */
+                TAIL(snew->fp_doc[f] + snew->fp_off[f][k], snew->fp_off[f][k + 1] - snew->fp_off[f][k], op);
+            }
+            if (!rc && j != so->nfid[f]) rc = MGPU_E_UNSUPPORTED;
+        }
+        for (int i = 0; i < snew->num_bools && !rc; i++)
+            for (int v = 0; v < 2; v++) TAIL(snew->bp_doc[i][v], snew->bp_n[i][v], m->bbase + 2u * (uint32_t)i + (uint32_t)v);
+#undef TAIL
+        off[P1] = at;
+        if (pass == 0) cap = at;
+    }
+    if (!rc) {
+        mgpu_shard_delta_t d;
+        memset(&d, 0, sizeof(d));
+        d.max_docid = snew->max_docid; d.num_postings = P1; d.old_pid = old_pid; d.post_off = off; d.post_doc = doc;
+        /* blobs of the new documents: rebased offsets */
+        const uint32_t nd = snew->max_docid - old_max;
+        uint64_t *ddo = malloc(sizeof(uint64_t) * ((size_t)nd + 1));
+        if (!ddo) rc = MGPU_E_LIMIT;
+        else {
+            const uint64_t base = snew->dd_off[old_max + 1];
+            for (uint32_t i = 0; i <= nd; i++) ddo[i] = snew->dd_off[old_max + 1 + i] - base;
+            d.dd_off = ddo; d.dd = snew->dd + base;
+            for (int i = 0; i < snew->num_numbers; i++) { d.np_n[i] = snew->np_n[i]; d.np_doc[i] = snew->np_doc[i]; }
+            rc = mgpu_shard_apply_delta(m->g, &d);
+            free(ddo);
+        }
+    }
+    free(old_pid); free(off); free(doc);
+    if (!rc && snew->dict && (snew->word_count != so->word_count || !m->gd)) {
+        /* words were added: the flat dictionary of the term lookup is exported again */
+        uint32_t *chars = NULL, *woff = NULL, *wwid = NULL, nw = 0;
+        if (mdict_export_words(snew->dict, &chars, &woff, &wwid, &nw)) rc = MGPU_E_ARG;
+        else {
+            mgpu_dict_t *gd = NULL;
+            rc = mgpu_dict_create(m->device, chars, woff, wwid, nw, &gd);
+            free(chars); free(woff); free(wwid);
+            if (!rc) { mgpu_dict_destroy(m->gd); m->gd = gd; }
+        }
+    }
+    if (!rc) {
+        m->s = snew; m->W = nm->W; m->T = nm->T; m->bbase = nm->bbase; m->num_postings = nm->num_postings;
+        memcpy(m->fbase, nm->fbase, sizeof(m->fbase));
+    }
+    free(nm);
+    return rc;
+}
+
 void mmirror_destroy(mmirror_t *m) {
     if (!m) return;
     mgpu_dict_destroy(m->gd);

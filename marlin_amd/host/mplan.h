@@ -33,6 +33,10 @@ typedef struct mmirror {
 /* pid 0 = all docs, 1..W = wid2bmap, W+1..W+T = twid2bmap, then facetid2bmap, then boolid2bmap */
 int  mmirror_create(const mshard_t *s, int device, mmirror_t **out);
 void mmirror_destroy(mmirror_t *m);
+/* row f-2: `snew` = the mirror's shard after a committed append-only bulk write; the mirror takes the difference as a
+ * delta (mgpu_shard_apply_delta) instead of being rebuilt.  No batch on this mirror may be in flight.  MGPU_E_LIMIT: no
+ * headroom left, nothing changed: mmirror_create a new one.  MGPU_E_UNSUPPORTED: not an append. */
+int  mmirror_apply_shard(mmirror_t *m, const mshard_t *snew);
 /* the posting-id scheme alone, no device memory (g and gd stay NULL): enough to build plans, e.g. in CPU-only tests */
 mmirror_t *mmirror_scheme(const mshard_t *s);
 
