@@ -102,7 +102,12 @@ static uint64_t tail_from(const uint32_t *a, uint64_t n, uint32_t lim) {
 int mmirror_apply_shard(mmirror_t *m, const mshard_t *snew) {
     if (!m || !m->g || !snew) return MGPU_E_ARG;
     const mshard_t *so = m->s;
-    if (so->has_used || snew->has_used) return MGPU_E_UNSUPPORTED;
+    /* a list of the docids in use (sdata->used_bmap) must only have grown at its end: no document deleted */
+    if (so->has_used != snew->has_used) return MGPU_E_UNSUPPORTED;
+    if (so->has_used) {
+        if (snew->used_n < so->used_n || tail_from(snew->used_doc, snew->used_n, so->max_docid) != so->used_n ||
+            memcmp(snew->used_doc, so->used_doc, so->used_n * sizeof(uint32_t))) return MGPU_E_UNSUPPORTED;
+    }
     if (snew->max_docid < so->max_docid || snew->word_count < so->word_count || snew->tword_count < so->tword_count ||
         snew->num_facets != so->num_facets || snew->num_numbers != so->num_numbers || snew->num_bools != so->num_bools) return MGPU_E_UNSUPPORTED;
     mmirror_t *nm = mmirror_scheme(snew);
@@ -111,7 +116,7 @@ int mmirror_apply_shard(mmirror_t *m, const mshard_t *snew) {
     uint32_t *old_pid = malloc(sizeof(uint32_t) * (size_t)(P1 ? P1 : 1));
     uint64_t *off = malloc(sizeof(uint64_t) * ((size_t)P1 + 1));
     /* an upper bound of the delta's size: every list's tail */
-    uint64_t cap = snew->max_docid - old_max, at = 0;
+    uint64_t cap = 0, at = 0;
     int rc = 0;
     if (!old_pid || !off) rc = MGPU_E_LIMIT;
     uint32_t *doc = NULL;
@@ -122,9 +127,16 @@ int mmirror_apply_shard(mmirror_t *m, const mshard_t *snew) {
         at = 0;
 #define TAIL(list, n, oldp) do { const uint32_t *l_ = (list); const uint64_t n_ = (n), t_ = tail_from(l_, n_, old_max); \
             off[p] = at; old_pid[p] = (oldp); if (pass == 1 && n_ > t_) memcpy(doc + at, l_ + t_, (n_ - t_) * sizeof(uint32_t)); at += n_ - t_; p++; } while (0)
-        off[p] = 0; old_pid[p] = 0;                                   /* pid 0: every docid */
-        if (pass == 1) for (uint32_t d = old_max + 1; d <= snew->max_docid; d++) doc[at + (d - old_max - 1)] = d;
-        at += snew->max_docid - old_max; p++;
+        off[p] = 0; old_pid[p] = 0;                                   /* pid 0: every docid in use */
+        if (snew->has_used) {
+            const uint64_t t0 = so->used_n, n0 = snew->used_n - t0;
+            if (pass == 1 && n0) memcpy(doc + at, snew->used_doc + t0, n0 * sizeof(uint32_t));
+            at += n0;
+        } else {
+            if (pass == 1) for (uint32_t d = old_max + 1; d <= snew->max_docid; d++) doc[at + (d - old_max - 1)] = d;
+            at += snew->max_docid - old_max;
+        }
+        p++;
         for (uint32_t w = 1; w <= nm->W; w++)
             TAIL(snew->wp_doc + snew->wp_off[w], snew->wp_off[w + 1] - snew->wp_off[w], w <= m->W ? w : 0xFFFFFFFFu);
         for (uint32_t t = 1; t <= nm->T; t++)

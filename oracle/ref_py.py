@@ -137,9 +137,10 @@ def run(ix, pqs, gpu=False, env=None, timeout=600):
     return parse_output(p.stdout, ix.num_shards, len(pqs))
 
 
-def run_two_writes(ix_a, ix_ab, pqs_a, pqs_ab, gpu=False, timeout=600):
+def run_two_writes(ix_a, ix_ab, pqs_a, pqs_ab, gpu=False, timeout=600, no_delta=False):
     """a second bulk write after the first queries: ix_ab holds ix_a's documents and more, in the same shards and order.
-    gpu: the mirror is attached after the first write and REFRESHED (mgpu_shim_refresh_shard) after the second.
+    gpu: the mirror is attached after the first write and REFRESHED (mgpu_shim_refresh_shard) after the second -- by a
+    delta (the call returns 0), or with no_delta (MGPU_SHIM_NO_DELTA=1) by a rebuild next to the live mirror (2).
     Returns (results of pqs_a on the first state, results of pqs_ab on the second)."""
     for s in range(ix_a.num_shards):
         assert ix_ab.docs[s][:len(ix_a.docs[s])] == ix_a.docs[s]
@@ -154,12 +155,15 @@ def run_two_writes(ix_a, ix_ab, pqs_a, pqs_ab, gpu=False, timeout=600):
             cmds.append("Y")
         for pq in pqs_ab:
             cmds += query_commands(ix_ab, pq)
+        env = dict(os.environ)
+        if no_delta:
+            env["MGPU_SHIM_NO_DELTA"] = "1"
         p = subprocess.run([EXE_GPU if gpu else EXE], input="\n".join(cmds) + "\n", text=True, stdout=subprocess.PIPE,
-                           stderr=subprocess.PIPE, timeout=timeout)
+                           stderr=subprocess.PIPE, timeout=timeout, env=env)
     if p.returncode != 0:
         raise RuntimeError("ref_query exited with %d\n%s\n%s" % (p.returncode, p.stdout[-2000:], p.stderr[-4000:]))
     allres = parse_output(p.stdout, ix_a.num_shards, len(pqs_a) + len(pqs_ab))
     refreshed = [ln.split() for ln in p.stdout.splitlines() if ln.startswith("refresh ")]
     if gpu:
-        assert len(refreshed) == ix_a.num_shards and all(t[2] == "0" for t in refreshed), refreshed
+        assert len(refreshed) == ix_a.num_shards and all(t[2] == ("2" if no_delta else "0") for t in refreshed), refreshed
     return allres[:len(pqs_a)], allres[len(pqs_a):]

@@ -231,13 +231,12 @@ static int attach_dict(struct dtrie *dt, int device, mgpu_dict_t **out) {
     return rc;
 }
 
-/* Mirrors one shard: every posting, docdata blob and num_dbi pair of its LMDB environment, read inside one read
- * transaction (a consistent snapshot against the single writer, sindex.c:184-254).  Replaces an earlier mirror of the
- * same shard.  Returns 0 or an MGPU_E_* code. */
-int mgpu_shim_attach_shard(struct shard *s, int device) {
+/* Every posting, docdata blob and num_dbi pair of a shard's LMDB environment, read inside one read transaction (a
+ * consistent snapshot against the single writer, sindex.c:184-254) into the host-side source of a mirror. */
+static int shim_read_shard(struct shard *s, mshard_t **src_out, size_t *txnid_out) {
     struct sindex *si = s->sindex;
     const struct mapping *map = si->map;
-    if (!map || device < 0 || device >= 64) return MGPU_E_ARG;
+    if (!map) return MGPU_E_ARG;
     MDB_txn *txn;
     if (mdb_txn_begin(si->env, NULL, MDB_RDONLY, &txn) != 0) return MGPU_E_ARG;
     const size_t snap_txnid = mdb_txn_id(txn);                      /* the commit this snapshot reflects */
@@ -283,11 +282,24 @@ int mgpu_shim_attach_shard(struct shard *s, int device) {
     mdb_txn_abort(txn);
     if (rc) { mbr_free(mb); M_ERR("gpu squery: mirroring shard %d failed (%d)", s->shard_id, rc); return rc; }
     mshard_t *src = mbr_finish(mb);
+    if (!src) return MGPU_E_LIMIT;
+    *src_out = src; *txnid_out = snap_txnid;
+    return 0;
+}
+
+/* Mirrors one shard (shim_read_shard + mmirror_create + the dictionary).  Replaces an earlier mirror of the same shard:
+ * the new one is built NEXT to the live one and swapped in.  Returns 0 or an MGPU_E_* code. */
+int mgpu_shim_attach_shard(struct shard *s, int device) {
+    struct sindex *si = s->sindex;
+    if (device < 0 || device >= 64) return MGPU_E_ARG;
+    mshard_t *src = NULL; size_t snap_txnid = 0;
+    int rc = shim_read_shard(s, &src, &snap_txnid);
+    if (rc) return rc;
     mmirror_t *mirror = NULL;
-    if (!src || (rc = mmirror_create(src, device, &mirror))) {
+    if ((rc = mmirror_create(src, device, &mirror))) {
         M_ERR("gpu squery: mmirror_create for shard %d: %s", s->shard_id, mgpu_last_error());
         mshard_free(src);
-        return rc ? rc : MGPU_E_LIMIT;
+        return rc;
     }
     /* the shard's dictionary for the device-side typo walk (the bridged mshard_t carries no dictionary of its own) */
     if ((rc = attach_dict(si->trie, device, &mirror->gd))) {
@@ -585,12 +597,17 @@ void execute_squery(void *w) {
     mgpu_shim_execute_squeries((struct squery *)w, 1);
 }
 
-/* Row f-2, the part that exists: refresh keyed on the commit.  Call where a bulk write ends (sindex.c:246).  When the
- * environment's last committed transaction is newer than the one the mirror was built from, a new mirror is built from
- * a fresh read snapshot NEXT to the live one -- queries keep running on the old mirror -- and swapped in under the
- * table's write lock (mgpu_shim_attach_shard: one locked section, the old generation dies with its last query);
- * otherwise nothing happens.  The rebuild is complete, not incremental.
- * Returns 0 (up to date or refreshed), 1 when the shard was never attached, or an MGPU_E_* code. */
+/* Row f-2: refresh keyed on the commit.  Call where a bulk write ends (sindex.c:246).  When the environment's last
+ * committed transaction is newer than the one the mirror reflects, the shard is read again from a fresh snapshot and the
+ * live mirror takes the DIFFERENCE as a delta (mmirror_apply_shard -> mgpu_shard_apply_delta: the new documents' records
+ * appended into the mirror's headroom, the posting array re-laid and its window index recomputed on the device; the
+ * dictionary mirror exported again only when the trie gained words).  The delta changes the mirror in place, so it runs
+ * with the shard's entry write-locked once the queries that hold the mirror have finished: queries wait for milliseconds
+ * instead of the device holding two mirrors for the seconds of a rebuild.  When the write was not an append (documents
+ * deleted or replaced) or the headroom is used up, the mirror is rebuilt next to the live one and swapped in
+ * (mgpu_shim_attach_shard), as before.  MGPU_SHIM_NO_DELTA=1 forces that path.
+ * Returns 0 (up to date, or refreshed by a delta), 2 (refreshed by a rebuild), 1 when the shard was never attached, or
+ * an MGPU_E_* code. */
 int mgpu_shim_refresh_shard(struct shard *s) {
     struct shim_mirror *gen = mirror_acquire(s);
     if (!gen) return 1;
@@ -599,7 +616,44 @@ int mgpu_shim_refresh_shard(struct shard *s) {
     MDB_envinfo info;
     if (mdb_env_info(s->sindex->env, &info) != 0) return MGPU_E_ARG;
     if (info.me_last_txnid <= have) return 0;
-    return mgpu_shim_attach_shard(s, device);
+    if (getenv("MGPU_SHIM_NO_DELTA")) { const int rc = mgpu_shim_attach_shard(s, device); return rc ? rc : 2; }
+    mshard_t *src = NULL; size_t snap_txnid = 0;
+    int rc = shim_read_shard(s, &src, &snap_txnid);
+    if (rc) return rc;
+    mgpu_dict_t *gd = NULL;
+    int applied = 0;
+    mshard_t *old_src = NULL;
+    pthread_rwlock_wrlock(&g_shards_lock);                          /* no query can pick the mirror up from here on */
+    struct shim_mirror *m = NULL;
+    for (int i = 0; i < g_nshards; i++) if (g_shards[i].shard == s) { m = g_shards[i].m; break; }
+    if (m) {
+        for (;;) {                                                  /* ... and those that hold it run to their end */
+            pthread_mutex_lock(&g_ref_lock);
+            const int busy = m->refs;
+            pthread_mutex_unlock(&g_ref_lock);
+            if (!busy) break;
+            struct timespec ts = { 0, 200000 };
+            nanosleep(&ts, NULL);
+        }
+        const uint32_t words_before = m->src->word_count;
+        rc = mmirror_apply_shard(m->mirror, src);
+        if (!rc) {
+            applied = 1;
+            old_src = m->src; m->src = src; m->txnid = snap_txnid;
+            if (src->word_count != words_before) {
+                /* the bridged shard carries no dictionary: the trie's word list is exported again */
+                if (!attach_dict(s->sindex->trie, device, &gd)) { mgpu_dict_destroy(m->mirror->gd); m->mirror->gd = gd; }
+                else M_ERR("gpu squery: dictionary of shard %d after a delta: %s", s->shard_id, mgpu_last_error());
+            }
+        }
+    }
+    pthread_rwlock_unlock(&g_shards_lock);
+    if (applied) { mshard_free(old_src); return 0; }
+    mshard_free(src);
+    if (!m) return 1;
+    if (rc != MGPU_E_LIMIT && rc != MGPU_E_UNSUPPORTED) { M_ERR("gpu squery: delta for shard %d: %s", s->shard_id, mgpu_last_error()); return rc; }
+    rc = mgpu_shim_attach_shard(s, device);
+    return rc ? rc : 2;
 }
 
 void sqresult_free(struct query *q, struct squery_result *sqres) {

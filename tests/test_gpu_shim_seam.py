@@ -96,10 +96,11 @@ def test_generated_queries_through_the_seam():
 
 
 def test_mirror_refresh_after_a_second_bulk_write():
-    """Row f-2, the trigger: documents indexed AFTER the mirror was attached (a second si_write_start .. si_write_end on
-    the same LMDB environments and dtrie) are invisible until mgpu_shim_refresh_shard sees the environment's newer
-    transaction id, rebuilds the mirror from a fresh read snapshot and swaps it in; the answers then equal the
-    reference's on the grown shard"""
+    """Row f-2 behind the reference's own writer: documents indexed AFTER the mirror was attached (a second si_write_start ..
+    si_write_end on the same LMDB environments and dtrie) are invisible until mgpu_shim_refresh_shard sees the environment's
+    newer transaction id, reads the shard again and hands the live mirror the difference as a delta
+    (mgpu_shard_apply_delta; the call reports 0) -- or, with MGPU_SHIM_NO_DELTA, rebuilds the mirror next to the live one and
+    swaps it in (2); either way the answers then equal the reference's on the grown shard"""
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import fuzz_parity
     rng = random.Random(79)
@@ -119,7 +120,9 @@ def test_mirror_refresh_after_a_second_bulk_write():
         w1, w2 = ref_py.run_two_writes(ix_a, ix_ab2, pa, pab)
         g1, g2 = ref_py.run_two_writes(ix_a, ix_ab2, pa, pab, gpu=True)
         compare_lists(pa, w1, g1, "before the second write")
-        compare_lists(pab, w2, g2, "after refresh")
+        compare_lists(pab, w2, g2, "after refresh (delta)")
+        g1r, g2r = ref_py.run_two_writes(ix_a, ix_ab2, pa, pab, gpu=True, no_delta=True)
+        compare_lists(pab, w2, g2r, "after refresh (rebuild)")
         assert any(x[0]["num_hits"] != y[0]["num_hits"] for x, y in zip(w1, w2)), "the second write changed nothing"
     finally:
         ix_a.close(); ix_ab.close(); ix_ab2.close()
