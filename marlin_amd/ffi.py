@@ -231,6 +231,7 @@ def load():
         "m_farmhash32_mk": (cu, [C.c_char_p, C.c_size_t]),
         "msynth_datagen": (vp, [cu, C.c_uint64, C.POINTER(C.c_char_p), ci, C.POINTER(cu)]),
         "msynth_zipf": (vp, [C.c_uint64, cu, cu, C.c_uint64, ci, ci]),
+        "msynth_zipf_first": (vp, [C.c_uint64, cu, cu, C.c_uint64, ci, ci, C.c_uint64]),
         "msynth_zipf_word": (ci, [cu, C.c_uint64, cu, C.c_char_p]),
         "msynth_route": (ci, [C.c_uint64, ci]),
         "mq_new": (C.POINTER(Query), [ci]),

@@ -672,6 +672,11 @@ int msynth_zipf_word(uint32_t vocab, uint64_t seed, uint32_t r, char *out) {
 
 mshard_t *msynth_zipf(uint64_t total_docs, uint32_t vocab, uint32_t hc_buckets, uint64_t seed,
                       int shard, int num_shards) {
+    return msynth_zipf_first(total_docs, vocab, hc_buckets, seed, shard, num_shards, total_docs);
+}
+/* the same corpus cut off after its first `first_docs` documents: what the shard held before the rest was written */
+mshard_t *msynth_zipf_first(uint64_t total_docs, uint32_t vocab, uint32_t hc_buckets, uint64_t seed,
+                            int shard, int num_shards, uint64_t first_docs) {
     /* strings: str | numbers: num, price | bools: flag | facets: cat, hc */
     mshard_builder_t *b = msb_new(1, 2, 1, 2);
     /* the vocabulary goes in first, so wid = rank + 1 in every shard */
@@ -689,7 +694,7 @@ mshard_t *msynth_zipf(uint64_t total_docs, uint32_t vocab, uint32_t hc_buckets, 
     const double lnv = log((double)vocab + 1.0);
     const double ln65 = log(65.0);
     char buf[32];
-    for (uint64_t g = 1; g <= total_docs; g++) {
+    for (uint64_t g = 1; g <= total_docs && g <= first_docs; g++) {
         if (msynth_route(g, num_shards) != shard) continue;
         uint64_t st = seed ^ (g * 0xA24BAED4963EE407ULL);
         msb_begin_doc(b);

@@ -125,6 +125,8 @@ mshard_t *msynth_datagen(uint32_t rend, uint64_t seed, const char **facets, int 
  * Documents global_first .. global_first+ndocs-1 that route to `shard` of `num_shards`. */
 mshard_t *msynth_zipf(uint64_t total_docs, uint32_t vocab, uint32_t hc_buckets, uint64_t seed,
                       int shard, int num_shards);
+mshard_t *msynth_zipf_first(uint64_t total_docs, uint32_t vocab, uint32_t hc_buckets, uint64_t seed,
+                            int shard, int num_shards, uint64_t first_docs);
 /* the vocabulary word with 0-based frequency rank r, written to out (returns length) */
 int msynth_zipf_word(uint32_t vocab, uint64_t seed, uint32_t r, char *out);
 /* shard routing used by the synthetic corpora (stand-in for get_shard_routing_id, utils.c:59-62) */
