@@ -296,6 +296,20 @@ uint64_t mgpu_dict_bytes(const mgpu_dict_t *d);
 int  mgpu_lookup_terms(mgpu_ctx_t *c, const mgpu_term_lookup_t *lookups, int n, mgpu_term_hit_t **hits, uint32_t *nhits);
 void mgpu_term_hits_free(mgpu_term_hit_t *hits);
 
+/* ------------------------------------------------------------------ f-4: hit materialisation, the matcher of highlight()
+ * form_result ends by highlighting the stored strings of every hit of the page (hit_query_processing,
+ * /root/reference/src/main/query.c:189-310 -> highlight(), highlight.c:215-345).  The compute of it is is_match
+ * (highlight.c:195-213) over every (token, query term) pair: levenshtein() (highlight.c:166-192) returns how many leading
+ * characters of the token match the term best, within the term's typo allowance.  mgpu_highlight_match does that for the
+ * tokens of ALL strings of ALL hits of a batch of queries in one launch, one lane per token: match_len[i] = the value
+ * is_match leaves in token i for the FIRST term of its job (query) that matches, or -1.  Tokenizing and mark assembly stay
+ * with the caller (marlin_amd/host/mhighlight.c: m_highlight_batch).  Tokens and terms are code points (at most 127 each);
+ * job j's terms are terms[job_term_off[j] .. job_term_off[j + 1]), in query order. */
+typedef struct mgpu_hl_term { uint32_t off, len; int32_t max_dist, prefix; } mgpu_hl_term_t;   /* off / len into term_chars */
+int mgpu_highlight_match(mgpu_ctx_t *c, const uint32_t *tok_chars, const uint32_t *tok_off /* [ntok + 1] */, const uint32_t *tok_job /* [ntok] */,
+                         uint32_t ntok, const mgpu_hl_term_t *terms, uint32_t nterms, const uint32_t *term_chars, uint32_t nterm_chars,
+                         const uint32_t *job_term_off /* [njobs + 1] */, uint32_t njobs, int32_t *match_len /* [ntok] */);
+
 /* ------------------------------------------------------------------ (e): the cross-GPU exchange
  * One process per GPU owns a block of the index's shards; after a batch every process holds fixed-size result slots
  * for its (query, shard) pairs and ONE all-gather hands every slot to every process, which then merges its share of the

@@ -46,6 +46,8 @@ void mgk_merge_postings(hipStream_t st, uint32_t num_postings, const uint32_t *o
                         const int32_t *old_dense, const unsigned long long *old_off, const uint32_t *old_doc,
                         const unsigned long long *delta_off, const uint32_t *delta_doc, uint32_t *new_doc,
                         const uint32_t *winbase, uint32_t nwin, uint32_t *post_win);
+void mgk_hl_match(hipStream_t st, const uint32_t *tok_chars, const uint32_t *tok_off, const uint32_t *tok_job, uint32_t ntok,
+                  const void *terms, const uint32_t *term_chars, const uint32_t *job_term_off, int32_t *out);
 void mgk_term_scan(hipStream_t st, const TermJob *jobs, const TermDict *dicts, uint32_t ndicts, uint32_t max_words, const uint32_t *term_chars,
                    uint2 *cand, uint32_t cand_cap, uint32_t *hits, uint32_t *counts, uint32_t cap);
 }
@@ -801,6 +803,7 @@ struct mgpu_ctx {
     char *lk_in = nullptr; size_t lk_in_cap = 0;
     uint32_t *lk_hits = nullptr; uint32_t lk_hits_cap = 0;
     uint32_t *lk_count = nullptr;
+    char *hl_buf = nullptr; size_t hl_cap = 0;                // highlight matcher (mgpu_highlight_match): inputs + result, grown on demand
     uint2 *lk_cand = nullptr; uint32_t lk_cand_cap = 0;      // (job, word) pairs the signature filter let through
     hipEvent_t ev[MGPU_NUM_STAGES + 1];
     int profiling;
@@ -856,6 +859,7 @@ extern "C" void mgpu_ctx_destroy(mgpu_ctx_t *c) {
     if (c->lk_hits) (void)hipFree(c->lk_hits);
     if (c->lk_count) (void)hipFree(c->lk_count);
     if (c->lk_cand) (void)hipFree(c->lk_cand);
+    if (c->hl_buf) (void)hipFree(c->hl_buf);
     for (int i = 0; i <= MGPU_NUM_STAGES; i++) (void)hipEventDestroy(c->ev[i]);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -2107,6 +2111,52 @@ extern "C" int mgpu_lookup_terms(mgpu_ctx_t *c, const mgpu_term_lookup_t *lookup
         *hits = h;
     }
     *nhits = total;
+    return MGPU_OK;
+}
+
+// ------------------------------------------------------------------ f-4: highlight matcher
+extern "C" int mgpu_highlight_match(mgpu_ctx_t *c, const uint32_t *tok_chars, const uint32_t *tok_off, const uint32_t *tok_job, uint32_t ntok,
+                                    const mgpu_hl_term_t *terms, uint32_t nterms, const uint32_t *term_chars, uint32_t nterm_chars,
+                                    const uint32_t *job_term_off, uint32_t njobs, int32_t *match_len) {
+    if (!c || !tok_off || (ntok && (!tok_job || !match_len)) || !job_term_off || (nterms && !terms)) return fail(MGPU_E_ARG, "null argument");
+    if (!ntok) return MGPU_OK;
+    if (c->pend && c->pend->active) return fail(MGPU_E_ARG, "a batch is in flight on this context");
+    // the kernel trusts the tables: check them here
+    if (tok_off[0] != 0) return fail(MGPU_E_ARG, "token offsets must start at 0");
+    for (uint32_t i = 0; i < ntok; i++) {
+        if (tok_off[i + 1] < tok_off[i]) return fail(MGPU_E_ARG, "token offsets must ascend");
+        if (tok_job[i] >= njobs) return fail(MGPU_E_ARG, "token names a job that does not exist");
+    }
+    for (uint32_t j = 0; j < njobs; j++) if (job_term_off[j + 1] < job_term_off[j] || job_term_off[j + 1] > nterms) return fail(MGPU_E_ARG, "job term ranges malformed");
+    for (uint32_t j = 0; j < nterms; j++) if ((uint64_t)terms[j].off + terms[j].len > nterm_chars) return fail(MGPU_E_ARG, "term beyond the term characters");
+    const size_t nchars = tok_off[ntok];
+    if (nchars && !tok_chars) return fail(MGPU_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t b_chars = al(std::max<size_t>(nchars, 1) * 4), b_off = al(((size_t)ntok + 1) * 4), b_job = al((size_t)ntok * 4),
+                 b_terms = al(std::max<size_t>(nterms, 1) * sizeof(mgpu_hl_term_t)), b_tch = al(std::max<size_t>(nterm_chars, 1) * 4),
+                 b_jto = al(((size_t)njobs + 1) * 4), b_out = al((size_t)ntok * 4);
+    const size_t need = b_chars + b_off + b_job + b_terms + b_tch + b_jto + b_out;
+    if (c->hl_cap < need) {
+        if (c->hl_buf) { (void)hipFree(c->hl_buf); c->hl_buf = nullptr; c->hl_cap = 0; }
+        const size_t cap = std::max<size_t>(need, (size_t)4 << 20);
+        HIPCHK(hipMalloc((void **)&c->hl_buf, cap));
+        c->hl_cap = cap;
+    }
+    char *p = c->hl_buf;
+    char *d_chars = p; p += b_chars; char *d_off = p; p += b_off; char *d_job = p; p += b_job; char *d_terms = p; p += b_terms;
+    char *d_tch = p; p += b_tch; char *d_jto = p; p += b_jto; char *d_out = p;
+    hipStream_t st = c->stream;
+    if (nchars) HIPCHK(hipMemcpyAsync(d_chars, tok_chars, nchars * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_off, tok_off, ((size_t)ntok + 1) * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_job, tok_job, (size_t)ntok * 4, hipMemcpyHostToDevice, st));
+    if (nterms) HIPCHK(hipMemcpyAsync(d_terms, terms, (size_t)nterms * sizeof(mgpu_hl_term_t), hipMemcpyHostToDevice, st));
+    if (nterm_chars) HIPCHK(hipMemcpyAsync(d_tch, term_chars, (size_t)nterm_chars * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_jto, job_term_off, ((size_t)njobs + 1) * 4, hipMemcpyHostToDevice, st));
+    mgk_hl_match(st, (const uint32_t *)d_chars, (const uint32_t *)d_off, (const uint32_t *)d_job, ntok, d_terms, (const uint32_t *)d_tch, (const uint32_t *)d_jto, (int32_t *)d_out);
+    HIPCHK(hipMemcpyAsync(match_len, d_out, (size_t)ntok * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
     return MGPU_OK;
 }
 

@@ -2518,6 +2518,70 @@ void mgk_scatter(hipStream_t st, const ScatterItem *items, uint32_t nitems) {
     uint32_t grid = nitems < 8192 ? nitems : 8192;
     hipLaunchKernelGGL(k_scatter, dim3(grid), dim3(MG_BLOCK), 0, st, items, nitems);
 }
+// ------------------------------------------------------------------ f-4: highlighting, the matcher
+// hit_query_processing (query.c:189-310) highlights the stored strings of every hit on the page: highlight() cuts a string
+// into tokens and tries every token against every query term with a prefix-returning Damerau-Levenshtein (is_match /
+// levenshtein, highlight.c:166-213).  A token's verdict -- the first term that matches and how many of its leading
+// characters the match covers -- depends on the token and the term set alone, so the tokens of all strings of all hits of
+// a batch of queries are matched in ONE launch, one lane per token; the tokenizer and the mark assembly (sequential per
+// string: overlap rule, snippet window) stay with the caller (marlin_amd/host/mhighlight.c).
+// The distance matrix is the reference's full (term + 1) x (token + 1) table, kept as three rows of bytes per lane in
+// LDS (values never exceed 254: strings are at most 127 characters).
+#define HL_MAXLEN 128
+struct HlTerm { uint32_t off, len; int32_t max_dist, prefix; };
+__global__ __launch_bounds__(64) void k_hl_match(const uint32_t *tok_chars, const uint32_t *tok_off, const uint32_t *tok_job, uint32_t ntok,
+                                                 const HlTerm *terms, const uint32_t *term_chars, const uint32_t *job_term_off, int32_t *out) {
+    __shared__ uint8_t rows[3 * HL_MAXLEN * 64];
+    const uint32_t lane = threadIdx.x, t = blockIdx.x * 64 + lane;
+    if (t >= ntok) return;
+    const uint32_t *s1 = tok_chars + tok_off[t];
+    const int s1len = (int)(tok_off[t + 1] - tok_off[t]);
+    int32_t res = -1;
+    if (s1len >= 1 && s1len < HL_MAXLEN) {
+        const uint32_t job = tok_job[t];
+        for (uint32_t j = job_term_off[job]; j < job_term_off[job + 1] && res < 0; j++) {
+            const HlTerm tm = terms[j];
+            const int s2len = (int)tm.len, max_dist = tm.max_dist;
+            if (s2len < 1 || s2len >= HL_MAXLEN) continue;
+            if (!tm.prefix && (s1len < s2len - max_dist || s1len > s2len + max_dist)) continue;          // is_match, highlight.c:199-203
+            const uint32_t *s2 = term_chars + tm.off;
+#define ROW(r, y) rows[((r) * HL_MAXLEN + (y)) * 64 + lane]
+            // row x of the table lives in rows[x % 3]
+            for (int y = 0; y <= s1len; y++) ROW(0, y) = (uint8_t)y;
+            int best_pos = 0xFF;
+            bool dead = false;
+            for (int x = 1; x <= s2len && !dead; x++) {
+                const int r = x % 3, r1 = (x + 2) % 3, r2 = (x + 1) % 3;
+                ROW(r, 0) = (uint8_t)x;
+                int best = 0xFF;
+                const uint32_t c2 = s2[x - 1], c2p = x > 1 ? s2[x - 2] : 0;
+                for (int y = 1; y <= s1len; y++) {
+                    const uint32_t c1 = s1[y - 1];
+                    const int cost = (c1 == c2) ? 0 : 1;
+                    int v = (int)ROW(r1, y) + 1;
+                    const int a = (int)ROW(r, y - 1) + 1, b = (int)ROW(r1, y - 1) + cost;
+                    if (a < v) v = a;
+                    if (b < v) v = b;
+                    if (x > 1 && y > 1 && c1 == c2p && s1[y - 2] == c2) {
+                        const int tt = (int)ROW(r2, y - 2) + cost;
+                        if (tt < v) v = tt;
+                    }
+                    ROW(r, y) = (uint8_t)v;
+                    if (v < best) { best = v; best_pos = y; }
+                }
+                if (best > max_dist) dead = true;
+            }
+#undef ROW
+            if (!dead && best_pos <= s1len) res = best_pos;
+        }
+    }
+    out[t] = res;
+}
+void mgk_hl_match(hipStream_t st, const uint32_t *tok_chars, const uint32_t *tok_off, const uint32_t *tok_job, uint32_t ntok,
+                  const void *terms, const uint32_t *term_chars, const uint32_t *job_term_off, int32_t *out) {
+    if (!ntok) return;
+    hipLaunchKernelGGL(k_hl_match, dim3((ntok + 63) / 64), dim3(64), 0, st, tok_chars, tok_off, tok_job, ntok, (const HlTerm *)terms, term_chars, job_term_off, out);
+}
 // ------------------------------------------------------------------ f-2: mirror maintenance
 // A committed bulk write (sindex.c:184-254: si_write_end stores the changed mbmaps, the new docdata blobs and num_dbi
 // entries) appends documents: every posting gains docids above the old maximum.  The mirror takes that as a delta

@@ -15,10 +15,12 @@ class GpuError(RuntimeError):
     pass
 
 
-def assemble(index, pq, sqres, form=None):
+def assemble(index, pq, sqres, form=None, page_batch=None):
     """sqres: ctypes array of SqResult, one per shard.  Returns a dict shaped like the
-    reference's response (query.c:312-422) without the stored documents' bodies.
-    form: the merge function (default: the product's m_form_result; the test oracle passes its own restatement)."""
+    reference's response (query.c:312-422).
+    form: the merge function (default: the product's m_form_result; the test oracle passes its own restatement).
+    page_batch: a hits.PageBatch: the page's documents come from their stored (zlib) values and their strings are
+    highlighted later, together with those of the batch's other queries, on the device."""
     lib = index.lib
     res = ffi.Result()
     (form or lib.m_form_result)(pq.q, sqres, index.num_shards, C.byref(res))
@@ -33,7 +35,13 @@ def assemble(index, pq, sqres, form=None):
         if res.page_s <= i < res.page_e:
             hit = {"_docid": r.docid, "_shard": r.shard_id}
             docs = index.docs[r.shard_id] if index.docs else None
-            if docs:
+            stored = index.stored[r.shard_id] if page_batch is not None and getattr(index, "stored", None) else None
+            if stored:
+                # the batch fills the marks in later: the hit must BE the object the recorder saw, not a copy of its keys
+                m = hits.materialize(lib, pq, stored[r.docid - 1], batch=page_batch)
+                m.update(hit)
+                hit = m
+            elif docs:
                 hit.update(hits.materialize(lib, pq, docs[r.docid - 1]))     # getFields + highlight (row f-4)
             if pq.explain:
                 hit["_explain"] = {k: rec[k] for k in ("typos", "proximity", "position", "exact", "field")}
@@ -333,8 +341,9 @@ class GpuEngine:
     def free_raw(self, outs):
         self.lib.m_sqresult_free_batch(outs, len(outs))
 
-    def search(self, pqs, capture=0, device_lookup=False):
-        """list of parsed queries -> list of assembled result dicts"""
+    def search(self, pqs, capture=0, device_lookup=False, device_highlight=False):
+        """list of parsed queries -> list of assembled result dicts.  device_highlight: the hits' documents are read from
+        their stored (zlib) values and the strings of all pages of the batch are highlighted with one device launch"""
         single = not isinstance(pqs, (list, tuple))
         if single:
             pqs = [pqs]
@@ -348,13 +357,16 @@ class GpuEngine:
         else:
             outs = self.execute_raw(pqs, capture)
         res = []
+        page_batch = hits.PageBatch(self.lib, self.ctx) if device_highlight else None
         for i, pq in enumerate(pqs):
             sub = (ffi.SqResult * ns).from_address(C.addressof(outs) + i * ns * C.sizeof(ffi.SqResult))
-            r = assemble(self.index, pq, sub)
+            r = assemble(self.index, pq, sub, page_batch=page_batch)
             if capture:
                 r["_shards"] = shard_results_to_py(self.index, pq, sub)
             res.append(r)
         self.free_raw(outs)
+        if page_batch is not None:
+            page_batch.flush()
         return res[0] if single else res
 
     def timing(self):

@@ -244,6 +244,7 @@ def load():
         "mq_add_agg": (ci, [C.POINTER(Query), ci, ci]),
         "m_highlight": (C.c_void_p, [C.c_char_p, C.POINTER(Query), ci]),
         "m_highlight_free": (None, [C.c_void_p]),
+        "m_highlight_batch": (ci, [vp, C.POINTER(C.c_char_p), C.POINTER(C.POINTER(Query)), C.POINTER(ci), ci, C.POINTER(C.c_void_p)]),
         "m_form_result": (None, [C.POINTER(Query), C.POINTER(SqResult), ci, C.POINTER(Result)]),
         "m_result_free": (None, [C.POINTER(Result)]),
         "m_sqresult_free": (None, [C.POINTER(SqResult)]),

@@ -9,9 +9,11 @@
  * here; bytes >= 0x80 are treated as token characters of one byte each.
  * Quirks kept: hyphenated words yield their parts AND the joined word as tokens; the transposition case adds `cost`,
  * not 1; text after the last token is not copied to the output; nothing matched -> NULL.
- * Host-only code: the JSON side (getFields projection, which strings to highlight) is in marlin_amd/hits.py.
+ * m_highlight is host-only code; m_highlight_batch runs the matcher for a whole batch of strings on the device
+ * (mgpu_highlight_match).  The JSON side (getFields projection, which strings to highlight) is in marlin_amd/hits.py.
  */
 #include "mquery.h"
+#include "marlin_gpu.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -127,10 +129,11 @@ static int is_match(hl_token_t *token, const m_term_t *t) {
     return token->is_match;
 }
 
-/* highlight.c:215-345; the result is malloc'd (m_highlight_free), NULL when nothing matched */
-char *m_highlight(const char *str, const m_query_t *q, int snip_num_words) {
-    hl_tokens_t ts = { NULL, 0, 0 };
-    tokenize(str, &ts);
+/* highlight.c:215-345 after the tokenizer.  pre == NULL: every token that the overlap rule lets through is tried against
+ * the terms here (is_match); otherwise pre[i] is token i's verdict, computed ahead for all tokens (the device matcher):
+ * the match length, or -1.  A token's verdict depends on the token and the terms alone, so both give the same marks. */
+static char *highlight_tokens(const char *str, const m_query_t *q, int snip_num_words, hl_tokens_t *tsp, const int32_t *pre) {
+    hl_tokens_t ts = *tsp;
     const int num_terms = q->num_terms, num_tokens = ts.n;
     int num_matches = 0;
     uint32_t last_match_end = 0;
@@ -138,7 +141,13 @@ char *m_highlight(const char *str, const m_query_t *q, int snip_num_words) {
     for (int i = 0; i < num_tokens; i++) {
         hl_token_t *t = &ts.v[i];
         if (t->se[0].start < last_match_end) continue;                     /* no overlapping marks */
-        for (int j = 0; j < num_terms; j++) {
+        if (pre) {
+            if (pre[i] >= 1 && pre[i] <= t->length) {
+                t->is_match = 1; t->match_len = pre[i];
+                num_matches++;
+                last_match_end = t->se[t->match_len - 1].end;
+            }
+        } else for (int j = 0; j < num_terms; j++) {
             if (is_match(t, &q->terms[j])) {
                 num_matches++;
                 last_match_end = t->se[t->match_len - 1].end;
@@ -184,9 +193,91 @@ char *m_highlight(const char *str, const m_query_t *q, int snip_num_words) {
         }
         resp[pos] = '\0';
     }
-    for (int i = 0; i < ts.n; i++) { free(ts.v[i].chars); free(ts.v[i].se); }
-    free(ts.v);
     return resp;
+}
+static void tokens_free(hl_tokens_t *ts) {
+    for (int i = 0; i < ts->n; i++) { free(ts->v[i].chars); free(ts->v[i].se); }
+    free(ts->v);
+    ts->v = NULL; ts->n = ts->cap = 0;
+}
+
+/* the result is malloc'd (m_highlight_free), NULL when nothing matched */
+char *m_highlight(const char *str, const m_query_t *q, int snip_num_words) {
+    hl_tokens_t ts = { NULL, 0, 0 };
+    tokenize(str, &ts);
+    char *resp = highlight_tokens(str, q, snip_num_words, &ts, NULL);
+    tokens_free(&ts);
+    return resp;
+}
+
+/* highlight() for n strings at once -- every string of every hit on the pages of a batch of queries (form_result's loop,
+ * query.c:385-401 -> hit_query_processing): strs[i] is highlighted for qs[i] (the same query object may repeat) with
+ * snip[i] (or 0 when snip is NULL).  The strings are cut into tokens here, ALL tokens are matched against their queries'
+ * terms in one device launch (mgpu_highlight_match on ctx, which must be idle), and the marks are assembled here.
+ * out[i] = malloc'd result (m_highlight_free) or NULL when nothing matched.  Returns 0 or an MGPU_E_* code. */
+int m_highlight_batch(mgpu_ctx_t *ctx, const char *const *strs, const m_query_t *const *qs, const int *snip, int n, char **out) {
+    if (n < 0 || (n && (!strs || !qs || !out))) return MGPU_E_ARG;
+    for (int i = 0; i < n; i++) out[i] = NULL;
+    if (!n) return 0;
+    hl_tokens_t *ts = calloc((size_t)n, sizeof(*ts));
+    uint32_t *job_of = malloc(sizeof(uint32_t) * (size_t)n);             /* string -> job (distinct query) */
+    const m_query_t **jobs = malloc(sizeof(*jobs) * (size_t)n);
+    int rc = (ts && job_of && jobs) ? 0 : MGPU_E_LIMIT;
+    uint32_t njobs = 0, ntok = 0, nterms = 0;
+    size_t nchars = 0, ntch = 0;
+    if (!rc) {
+        for (int i = 0; i < n; i++) {
+            /* the pages of one query come together: looking at the last job is enough to fold them */
+            if (njobs && jobs[njobs - 1] == qs[i]) job_of[i] = njobs - 1;
+            else { jobs[njobs] = qs[i]; job_of[i] = njobs++; }
+            tokenize(strs[i], &ts[i]);
+            ntok += (uint32_t)ts[i].n;
+            for (int k = 0; k < ts[i].n; k++) nchars += (size_t)ts[i].v[k].length;
+        }
+        for (uint32_t j = 0; j < njobs; j++) { nterms += (uint32_t)jobs[j]->num_terms; for (int t = 0; t < jobs[j]->num_terms; t++) ntch += (size_t)jobs[j]->terms[t].word.length; }
+    }
+    int32_t *pre = NULL;
+    if (!rc && ntok) {
+        uint32_t *tok_chars = malloc(sizeof(uint32_t) * (nchars ? nchars : 1)), *tok_off = malloc(sizeof(uint32_t) * ((size_t)ntok + 1)),
+                 *tok_job = malloc(sizeof(uint32_t) * (size_t)ntok), *term_chars = malloc(sizeof(uint32_t) * (ntch ? ntch : 1)),
+                 *jto = malloc(sizeof(uint32_t) * ((size_t)njobs + 1));
+        mgpu_hl_term_t *terms = malloc(sizeof(*terms) * (nterms ? nterms : 1));
+        pre = malloc(sizeof(int32_t) * (size_t)ntok);
+        if (!tok_chars || !tok_off || !tok_job || !term_chars || !jto || !terms || !pre) rc = MGPU_E_LIMIT;
+        else {
+            uint32_t at = 0, k = 0;
+            for (int i = 0; i < n; i++)
+                for (int x = 0; x < ts[i].n; x++) {
+                    tok_off[k] = at; tok_job[k] = job_of[i]; k++;
+                    memcpy(tok_chars + at, ts[i].v[x].chars, sizeof(uint32_t) * (size_t)ts[i].v[x].length); at += (uint32_t)ts[i].v[x].length;
+                }
+            tok_off[k] = at;
+            uint32_t ta = 0, tn = 0;
+            for (uint32_t j = 0; j < njobs; j++) {
+                jto[j] = tn;
+                for (int t = 0; t < jobs[j]->num_terms; t++) {
+                    const m_term_t *tm = &jobs[j]->terms[t];
+                    terms[tn].off = ta; terms[tn].len = (uint32_t)tm->word.length; terms[tn].prefix = tm->prefix ? 1 : 0;
+                    terms[tn].max_dist = tm->typos ? (tm->word.length > 7 ? 2 : (tm->word.length > 3 ? 1 : 0)) : 0;     /* is_match, highlight.c:196-198 */
+                    memcpy(term_chars + ta, tm->word.chars, sizeof(uint32_t) * (size_t)tm->word.length); ta += (uint32_t)tm->word.length;
+                    tn++;
+                }
+            }
+            jto[njobs] = tn;
+            rc = mgpu_highlight_match(ctx, tok_chars, tok_off, tok_job, ntok, terms, nterms, term_chars, (uint32_t)ntch, jto, njobs, pre);
+        }
+        free(tok_chars); free(tok_off); free(tok_job); free(term_chars); free(jto); free(terms);
+    }
+    if (!rc) {
+        uint32_t k = 0;
+        for (int i = 0; i < n; i++) {
+            if (ts[i].n) out[i] = highlight_tokens(strs[i], qs[i], snip ? snip[i] : 0, &ts[i], pre + k);
+            k += (uint32_t)ts[i].n;
+        }
+    }
+    if (ts) for (int i = 0; i < n; i++) tokens_free(&ts[i]);
+    free(ts); free(job_of); free(jobs); free(pre);
+    return rc;
 }
 
 void m_highlight_free(char *s) { free(s); }

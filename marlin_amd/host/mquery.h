@@ -55,6 +55,9 @@ void m_result_free(m_result_t *r);
  * <mark> </mark>, or NULL when nothing matches; snip_num_words as in the reference (its callers pass 0).  mhighlight.c */
 char *m_highlight(const char *str, const m_query_t *q, int snip_num_words);
 void  m_highlight_free(char *s);
+/* the same for n strings with the matcher on the device (one launch for all tokens); ctx idle, on any device */
+struct mgpu_ctx;
+int   m_highlight_batch(struct mgpu_ctx *ctx, const char *const *strs, const m_query_t *const *qs, const int *snip, int n, char **out);
 
 /* __sort_lt (sort.c:46-100) */
 bool m_rank_lt(const m_docrank_t *a, const m_docrank_t *b, const int *rules);

@@ -55,6 +55,7 @@ class Index:
         self.strings, self.numbers, self.bools, self.facets = [], [], [], []
         self.shards = []          # mshard_t* (c_void_p)
         self.docs = []            # per shard: list of original docs, docid-1 indexed
+        self.stored = []          # per shard: the docid2json values of the same documents (hits.pack_stored), docid-1 indexed
         self.mirrors = None
         self._ready = False
 
@@ -110,11 +111,13 @@ class Index:
         builders = [lib.msb_new(len(self.strings), len(self.numbers), len(self.bools), len(self.facets))
                     for _ in range(self.num_shards)]
         self.docs = [[] for _ in range(self.num_shards)]
+        self.stored = [[] for _ in range(self.num_shards)]
         for n, d in enumerate(docs):
             s = self.route(d, n)
             b = builders[s]
             lib.msb_begin_doc(b)
             self.docs[s].append(d)
+            self.stored[s].append(hits.pack_stored(d))
             for k, v in d.items():                       # parse_index_document, sindex.c:792-893
                 f = self.fields.get(k)
                 if f is None or not (f.is_indexed or f.is_facet) or _value_type(v) != f.type:

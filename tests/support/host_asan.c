@@ -19,6 +19,14 @@ static void gen_text(char *buf, int maxlen, const char *alpha) {
     buf[n] = 0;
 }
 
+/* no GPU library is linked into this driver: the one device entry point mhighlight.c names (m_highlight_batch's matcher)
+ * is never reached here */
+int mgpu_highlight_match(void *c, const uint32_t *a, const uint32_t *b, const uint32_t *d, uint32_t n, const void *t, uint32_t nt,
+                         const uint32_t *tc, uint32_t ntc, const uint32_t *jo, uint32_t nj, int32_t *out) {
+    (void)c; (void)a; (void)b; (void)d; (void)n; (void)t; (void)nt; (void)tc; (void)ntc; (void)jo; (void)nj; (void)out;
+    return -1;
+}
+
 int main(void) {
     long marks = 0, strings = 0;
     const char *alpha = "aaabbcdeAB  .-'_9,!";
