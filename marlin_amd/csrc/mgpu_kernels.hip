@@ -855,7 +855,7 @@ __global__ __launch_bounds__(MG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
     __shared__ double s_val[MG_BLOCK];
     __shared__ uint32_t s_nord[MGPU_MAX_FIELDS];      // ordinals per facet field of the squery in hand (the ordinal guard's extents)
     __shared__ uint2 s_match[MG_BLOCK * MG_MCAP];
-    __shared__ uint32_t s_pairs[MG_BLOCK * MG_PCAP];
+    __shared__ uint32_t s_pairs[MG_BLOCK * (MG_PCAP + 1)];         // + a spare row that takes the staging's out-of-range words
     const uint32_t ntiles = *tile_count;
     const int skip = mg_dbg_skip;
     const uint32_t tid = threadIdx.x;
@@ -926,6 +926,14 @@ __global__ __launch_bounds__(MG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
             // two explicit probe paths: through a runtime-selected pointer the compiler would emit
             // flat loads (LDS or global decided per access) and wait on each one
             const bool tab_in_lds = do_rank && hmask < MG_LDS_HASH;
+            // facet staging (phase 1): the rows of s_pairs that this lane's four record words go to (the spare row for
+            // words outside the section's first MG_PCAP)
+            const int fx0 = 4 * (int)gl - (int)(4 + 2 * rec_nnum);
+            const bool stage_lane = fx0 > -4 && fx0 < MG_PCAP;
+            const uint32_t srow0 = (uint32_t)((fx0 >= 0 && fx0 < MG_PCAP) ? fx0 : MG_PCAP) * MG_BLOCK;
+            const uint32_t srow1 = (uint32_t)((fx0 + 1 >= 0 && fx0 + 1 < MG_PCAP) ? fx0 + 1 : MG_PCAP) * MG_BLOCK;
+            const uint32_t srow2 = (uint32_t)((fx0 + 2 >= 0 && fx0 + 2 < MG_PCAP) ? fx0 + 2 : MG_PCAP) * MG_BLOCK;
+            const uint32_t srow3 = (uint32_t)((fx0 + 3 >= 0 && fx0 + 3 < MG_PCAP) ? fx0 + 3 : MG_PCAP) * MG_BLOCK;
             const uint32_t gshift = tid & 48u;                     // the group's first bit in a wave ballot
             const uint32_t gbelow = (1u << gl) - 1u;               // the group's lanes below this one
             // match records are r-major (record r of document d at [r * MG_BLOCK + d]): phase 2 reads its document's
@@ -958,33 +966,42 @@ __global__ __launch_bounds__(MG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                 // headers (lane 0 of the group holds them), rank value, and which of the lane's two 8-byte
                 // slots are docword entries
                 uint32_t in_a = 0, in_b = 0, tail = 0;
+                const uint32_t dbase = grp * 16 + half * 8;
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
-                    const uint32_t d = grp * 16 + half * 8 + k;
-                    const uint32_t h0 = __shfl(v[k].x, 0, 16), h1 = __shfl(v[k].y, 0, 16);
-                    const uint32_t h3 = __shfl(v[k].w, 0, 16);
+                    const uint32_t h0 = __shfl(v[k].x, 0, 16), h3 = __shfl(v[k].w, 0, 16);
                     const uint32_t nin = h0 >> 16, ws = h3 >> 16;
-                    if (gl == 0) s_pbase[d] = h1;
-                    if (fac_here) {
-                        // the record's facet section (from word 4 + 2 * rec_nnum) is staged in the pair slices,
-                        // which are idle until phase 1b; s_np carries "the section is in the record"
-                        if (gl == 0) s_np[d] = (h3 >> 8) & 1u;
-                        const int x0 = 4 * (int)gl - (int)(4 + 2 * rec_nnum);
-                        if (x0 > -4 && x0 < MG_PCAP) {
-                            if (x0 >= 0 && x0 < MG_PCAP) s_pairs[x0 * MG_BLOCK + d] = v[k].x;
-                            if (x0 + 1 >= 0 && x0 + 1 < MG_PCAP) s_pairs[(x0 + 1) * MG_BLOCK + d] = v[k].y;
-                            if (x0 + 2 >= 0 && x0 + 2 < MG_PCAP) s_pairs[(x0 + 2) * MG_BLOCK + d] = v[k].z;
-                            if (x0 + 3 >= 0 && x0 + 3 < MG_PCAP) s_pairs[(x0 + 3) * MG_BLOCK + d] = v[k].w;
-                        }
-                    }
-                    if (val_in_rec && gl == (uint32_t)(1 + (rb >> 1))) {
-                        const u64 bits = (rb & 1) ? (((u64)v[k].w << 32) | v[k].z) : (((u64)v[k].y << 32) | v[k].x);
-                        s_val[d] = __longlong_as_double((long long)bits);
-                    }
                     const uint32_t s0 = 2 * gl;
-                    if (s0 >= ws && s0 < ws + nin) in_a |= 1u << k;
-                    if (s0 + 1 >= ws && s0 + 1 < ws + nin) in_b |= 1u << k;
-                    if (nin + ws > 32 || (h0 & 0xFFFFu) > nin) tail |= 1u << k;
+                    // ws <= slot < ws + nin as one unsigned compare; no branches in this loop
+                    in_a |= (s0 - ws < nin ? 1u : 0u) << k;
+                    in_b |= (s0 + 1u - ws < nin ? 1u : 0u) << k;
+                    tail |= ((nin + ws > 32 || (h0 & 0xFFFFu) > nin) ? 1u : 0u) << k;
+                }
+                // What single lanes of the group copy out of the record runs as ONE predicated region per role with the
+                // eight documents inside (the roles do not depend on k), instead of a handful of regions per document:
+                // exec-mask bookkeeping is most of this kernel's scalar instructions.
+                if (gl == 0) {
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        s_pbase[dbase + k] = v[k].y;
+                        if (fac_here) s_np[dbase + k] = (v[k].w >> 8) & 1u;       // "the facet section is in the record"
+                    }
+                }
+                if (fac_here && stage_lane) {
+                    // the record's facet section (from word 4 + 2 * rec_nnum) is staged in the pair slices, which are
+                    // idle until phase 2
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        s_pairs[srow0 + dbase + k] = v[k].x; s_pairs[srow1 + dbase + k] = v[k].y;
+                        s_pairs[srow2 + dbase + k] = v[k].z; s_pairs[srow3 + dbase + k] = v[k].w;
+                    }
+                }
+                if (val_in_rec && gl == (uint32_t)(1 + (rb >> 1))) {
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const u64 bits = (rb & 1) ? (((u64)v[k].w << 32) | v[k].z) : (((u64)v[k].y << 32) | v[k].x);
+                        s_val[dbase + k] = __longlong_as_double((long long)bits);
+                    }
                 }
                 if (do_rank && !(skip & 4)) {
                     if (tab_in_lds) {
