@@ -1120,8 +1120,10 @@ __global__ __launch_bounds__(MG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
 #endif
                     uint32_t p0[MG_MCAP], p1[MG_MCAP], p2[MG_MCAP];
 #pragma unroll
+                    for (int r = 0; r < MG_MCAP; r++) { p0[r] = 0; p1[r] = 0; p2[r] = 0; }
+#pragma unroll
                     for (int r = 0; r < MG_MCAP; r++) {
-                        p0[r] = 0; p1[r] = 0; p2[r] = 0;
+                        if (!__any((uint32_t)r < cnt)) break;                 // nobody in the wave has this many records
                         if ((uint32_t)r < cnt) {
                             const uint2 m = s_match[r * MG_BLOCK + tid];
                             const uint32_t info = m.y;
@@ -1142,6 +1144,7 @@ __global__ __launch_bounds__(MG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                     LdsPairs ps = {&s_pairs[tid], MG_PCAP};
 #pragma unroll
                     for (int r = 0; r < MG_MCAP; r++) {
+                        if (!__any((uint32_t)r < cnt)) break;
                         if ((uint32_t)r >= cnt) continue;
                         const uint2 m = s_match[r * MG_BLOCK + tid];
                         rank_reduce(st, nw, nt, m.x, p0[r]);
@@ -1153,13 +1156,25 @@ __global__ __launch_bounds__(MG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                         const uint32_t per = (keep_a ? 1u : 0u) + (slot_b >= 0 ? 1u : 0u);
                         if (!per) continue;
                         if ((uint32_t)st.np + per * pc > MG_PCAP) { st.ovf = true; continue; }
-                        const uint32_t *pd = pdoc + (info >> 9);
-                        for (uint32_t j = 0; j < pc; j++) {
-                            if (j > 2 && !CK(3, x_pbase + (info >> 9) + j, x_pext)) break;
-                            const uint32_t pv = (j == 0) ? p0[r] : (j == 1) ? p1[r] : (j == 2) ? p2[r] : pd[j];
-                            if (keep_a) ps.set(st.np++, ((uint32_t)slot_a << 24) | pv);
-                            if (slot_b >= 0) ps.set(st.np++, ((uint32_t)slot_b << 24) | pv);
+                        // Both pairs of a position are stored unconditionally and the cursor moves past the ones that count: a
+                        // store that does not count is overwritten by the next one, and the last one lands at most in the
+                        // spare row (np + per * pc <= MG_PCAP was checked above, so np never passes MG_PCAP).  A record with
+                        // no position at all (pc == 0: no writer makes one) stores nothing.
+                        const uint32_t sa = (uint32_t)slot_a << 24, sb = (uint32_t)slot_b << 24;
+                        const int ia = keep_a ? 1 : 0, ib = slot_b >= 0 ? 1 : 0;
+                        int np = st.np;
+                        if (pc > 0) { ps.set(np, sa | p0[r]); np += ia; ps.set(np, sb | p0[r]); np += ib; }
+                        if (pc > 1) { ps.set(np, sa | p1[r]); np += ia; ps.set(np, sb | p1[r]); np += ib; }
+                        if (pc > 2) { ps.set(np, sa | p2[r]); np += ia; ps.set(np, sb | p2[r]); np += ib; }
+                        if (pc > 3) {
+                            const uint32_t *pd = pdoc + (info >> 9);
+                            for (uint32_t j = 3; j < pc; j++) {
+                                if (!CK(3, x_pbase + (info >> 9) + j, x_pext)) break;
+                                const uint32_t pv = pd[j];
+                                ps.set(np, sa | pv); np += ia; ps.set(np, sb | pv); np += ib;
+                            }
                         }
+                        st.np = np;
                     }
                     if (st.ovf) ok = false; else rank_finish(st, nw, exact_present, ps, ro);
                 }
