@@ -1243,114 +1243,141 @@ __global__ __launch_bounds__(MG_BLOCK) void k_rank_overflow(const SqDev *sqs, co
 // pre: 1 = the pass BEFORE a fast-ranked squery's hit list is replaced by its sample: aggregations only, and only for
 // squeries whose fast_flag is set (calculate_agg over all matching documents, docrank.c:553-557); 0 = the normal pass,
 // in which those squeries count facets only (perform_doc_processing, docrank.c:409).
+#define DP_ITEMS 256                         // work items a workgroup looks at at a time
 __global__ __launch_bounds__(MG_BLOCK) void k_docproc(const SqDev *sqs, const uint2 *tile_list, const uint32_t *tile_count, uint32_t lds_bins, int pre) {
     uint32_t *hist = (uint32_t *)dyn_tab;        // lds_bins words of dynamic LDS: the largest field of the batch that is privatised
     __shared__ AggPart red[MG_BLOCK / 64];
+    __shared__ uint2 s_items[DP_ITEMS];
     const uint32_t ntiles = *tile_count;
-    for (uint32_t w = blockIdx.x; w < ntiles; w += gridDim.x) {
-        // the work item is the same for every lane: say so, so that the descriptor is read with scalar loads
-        const uint2 item_v = tile_list[w];
-        const uint2 item = make_uint2(__builtin_amdgcn_readfirstlane(item_v.x), __builtin_amdgcn_readfirstlane(item_v.y));
-        const SqDev &sq = sqs[item.x];
-        // The hit list is cut into nproc_blocks interleaved slices (fixed by the shard size so that
-        // the f64 reduction tree never depends on the batch); work item (sq, vb) is slice vb, and
-        // tiles beyond the slice count have nothing to add.
-        const uint32_t nvb = sq.nproc_blocks, vb = item.y;
-        if (vb >= nvb || (sq.hist_mask == 0 && sq.num_aggs == 0)) continue;
-        const bool fast = sq.fast_eligible && *sq.fast_flag;
-        if (pre && !(fast && sq.num_aggs)) continue;
-        const bool have_ords = sq.fac_in_rank != 0;
-        const uint32_t M = *sq.num_hits;
-        const uint32_t stride = nvb * MG_BLOCK;
+    // A workgroup takes a run of consecutive work items: a squery's items sit together on the list (k_order), so the
+    // privatised histogram of a field is zeroed and flushed once per squery and run instead of once per 256 hits -- the
+    // flush is one returning global atomic per non-empty bin (first touch is remembered), which was most of this kernel.
+    const uint32_t per = (ntiles + gridDim.x - 1) / gridDim.x;
+    const uint32_t run_end = (blockIdx.x + 1) * per < ntiles ? (blockIdx.x + 1) * per : ntiles;
+    for (uint32_t c0 = blockIdx.x * per; c0 < run_end; c0 += DP_ITEMS) {
+        const uint32_t nc = run_end - c0 < DP_ITEMS ? run_end - c0 : DP_ITEMS;
+        __syncthreads();
+        if (threadIdx.x < nc) s_items[threadIdx.x] = tile_list[c0 + threadIdx.x];
+        __syncthreads();
+        uint32_t x0 = 0;
+        while (x0 < nc) {
+            // [x0, x1): the items of one squery
+            const uint32_t sqi = __builtin_amdgcn_readfirstlane(s_items[x0].x);
+            uint32_t x1 = x0 + 1;
+            while (x1 < nc && __builtin_amdgcn_readfirstlane(s_items[x1].x) == sqi) x1++;
+            const SqDev &sq = sqs[sqi];
+            // The hit list is cut into nproc_blocks interleaved slices (fixed by the shard size so that
+            // the f64 reduction tree never depends on the batch); work item (sq, vb) is slice vb, and
+            // tiles beyond the slice count have nothing to add.
+            const uint32_t nvb = sq.nproc_blocks;
+            const bool fast = sq.fast_eligible && *sq.fast_flag;
+            const bool skip_all = (sq.hist_mask == 0 && sq.num_aggs == 0) || (pre && !(fast && sq.num_aggs));
+            if (skip_all) { x0 = x1; continue; }
+            const bool have_ords = sq.fac_in_rank != 0;
+            const uint32_t M = *sq.num_hits;
+            const uint32_t stride = nvb * MG_BLOCK;
+            const uint32_t S4 = sq.sh.rec_stride >> 2;
+            const uint32_t *rec = sq.sh.rec;
+            const uint32_t nnum_in = sq.sh.rec_nnum;
+            const uint32_t *hits = sq.hits;
+            const int nfac = sq.sh.num_facets, naggs = sq.num_aggs;
+            const uint32_t hist_mask = sq.hist_mask, fdirect_mask = sq.fdirect_mask;
+            uint32_t *err = sq.err;
+            for (int f = 0; f < nfac; f++) {
+                if (pre || !((hist_mask >> f) & 1u) || ((fdirect_mask >> f) & 1u)) continue;
+                const uint32_t nord = sq.sh.fa_nord[f];
+                const uint32_t *off = sq.sh.fa_off[f];
+                const uint32_t *ord = sq.sh.fa_ord[f];
+                uint32_t *gh = sq.hist[f];
+                uint32_t *tl = sq.touched[f], *tn = sq.ntouched[f];
+                const bool use_lds = nord <= lds_bins;
+                if (use_lds) {
+                    for (uint32_t i = threadIdx.x; i < nord; i += MG_BLOCK) hist[i] = 0;
+                    __syncthreads();
+                }
+                const uint32_t *ords = have_ords ? sq.fac_ord[f] : nullptr;
+                for (uint32_t x = x0; x < x1; x++) {
+                    const uint32_t vb = __builtin_amdgcn_readfirstlane(s_items[x].y);
+                    if (vb >= nvb) continue;
+                    for (uint32_t i = vb * MG_BLOCK + threadIdx.x; i < M; i += stride) {
+                        // the rank kernel left the hit's ordinal behind (one value, the common case) ...
+                        const uint32_t code = have_ords ? ords[i] : MG_FAC_LOOKUP;
+                        if (code == MG_FAC_NONE) continue;
+                        if (code != MG_FAC_LOOKUP) {
+                            if (!mg_ck_always(err, 9, code, nord)) continue;              // permanent guard: see k_rank_tile, site 4
+                            if (use_lds) atomicAdd(&hist[code], 1u);
+                            else wave_append(atomicAdd(&gh[code], 1u) == 0, code, tl, tn);
+                            continue;
+                        }
+                        // ... else the document's ordinals for field f come from its record when they fit there, else
+                        // from the per-field CSR
+                        const uint32_t d = hits[i];
+                        const uint32_t *r = rec + (size_t)d * S4;
+                        const uint32_t *vals; uint32_t cnt;
+                        if ((r[3] >> 8) & 1u) {
+                            const uint32_t *fp = r + 4 + 2 * nnum_in;
+                            for (int g = 0; g < f; g++) fp += 1 + fp[0];
+                            cnt = fp[0]; vals = fp + 1;
+                        } else { const uint32_t a0 = off[d]; cnt = off[d + 1] - a0; vals = ord + a0; }
+                        for (uint32_t j = 0; j < cnt; j++) {
+                            const uint32_t o = vals[j];
+                            if (use_lds) atomicAdd(&hist[o], 1u);
+                            else wave_append(atomicAdd(&gh[o], 1u) == 0, o, tl, tn);          // first touch: remember the bin
+                        }
+                    }
+                }
+                if (use_lds) {
+                    __syncthreads();
+                    for (uint32_t i0 = 0; i0 < nord; i0 += MG_BLOCK) {
+                        const uint32_t i = i0 + threadIdx.x;
+                        const uint32_t c = i < nord ? hist[i] : 0;
+                        wave_append(c && atomicAdd(&gh[i], c) == 0, i, tl, tn);
+                    }
+                    __syncthreads();
+                }
+            }
 
-        const uint32_t S4 = sq.sh.rec_stride >> 2;
-        const uint32_t *rec = sq.sh.rec;
-        const uint32_t nnum_in = sq.sh.rec_nnum;
-        for (int f = 0; f < sq.sh.num_facets; f++) {
-            if (pre || !((sq.hist_mask >> f) & 1u) || ((sq.fdirect_mask >> f) & 1u)) continue;
-            const uint32_t nord = sq.sh.fa_nord[f];
-            const uint32_t *off = sq.sh.fa_off[f];
-            const uint32_t *ord = sq.sh.fa_ord[f];
-            uint32_t *gh = sq.hist[f];
-            uint32_t *tl = sq.touched[f], *tn = sq.ntouched[f];
-            const bool use_lds = nord <= lds_bins;
-            if (use_lds) {
-                for (uint32_t i = threadIdx.x; i < nord; i += MG_BLOCK) hist[i] = 0;
-                __syncthreads();
-            }
-            const uint32_t *ords = have_ords ? sq.fac_ord[f] : nullptr;
-            for (uint32_t i = vb * MG_BLOCK + threadIdx.x; i < M; i += stride) {
-                // the rank kernel left the hit's ordinal behind (one value, the common case) ...
-                const uint32_t code = have_ords ? ords[i] : MG_FAC_LOOKUP;
-                if (code == MG_FAC_NONE) continue;
-                if (code != MG_FAC_LOOKUP) {
-                    if (!mg_ck_always(sq.err, 9, code, nord)) continue;              // permanent guard: see k_rank_tile, site 4
-                    if (use_lds) atomicAdd(&hist[code], 1u);
-                    else wave_append(atomicAdd(&gh[code], 1u) == 0, code, tl, tn);
-                    continue;
-                }
-                // ... else the document's ordinals for field f come from its record when they fit there, else
-                // from the per-field CSR
-                const uint32_t d = sq.hits[i];
-                const uint32_t *r = rec + (size_t)d * S4;
-                const uint32_t *vals; uint32_t cnt;
-                if ((r[3] >> 8) & 1u) {
-                    const uint32_t *fp = r + 4 + 2 * nnum_in;
-                    for (int g = 0; g < f; g++) fp += 1 + fp[0];
-                    cnt = fp[0]; vals = fp + 1;
-                } else { const uint32_t a0 = off[d]; cnt = off[d + 1] - a0; vals = ord + a0; }
-                for (uint32_t j = 0; j < cnt; j++) {
-                    const uint32_t o = vals[j];
-                    if (use_lds) atomicAdd(&hist[o], 1u);
-                    else wave_append(atomicAdd(&gh[o], 1u) == 0, o, tl, tn);          // first touch: remember the bin
-                }
-            }
-            if (use_lds) {
-                __syncthreads();
-                for (uint32_t i0 = 0; i0 < nord; i0 += MG_BLOCK) {
-                    const uint32_t i = i0 + threadIdx.x;
-                    const uint32_t c = i < nord ? hist[i] : 0;
-                    wave_append(c && atomicAdd(&gh[i], c) == 0, i, tl, tn);
-                }
-                __syncthreads();
-            }
-        }
-
-        for (int a = 0; a < sq.num_aggs; a++) {
-            if (sq.agg_type[a] == MGPU_A_CARDINALITY) continue;
-            if (fast && !pre) continue;                  // aggregated before the sample replaced the hit list
-            const uint32_t af = (uint32_t)sq.agg_field[a];
-            const uint64_t *grp = fast ? sq.sh.grp_has[af] : nullptr;    // fast mode reads idnum2dbl: a missing group = no value
-            const double *col = sq.sh.num_col[af];
-            const bool in_rec = af < nnum_in;
-            double sum = 0.0, mn = 1.7976931348623157e308, mx = -1.7976931348623157e308;
-            unsigned long long cnt = 0;
-            for (uint32_t i = vb * MG_BLOCK + threadIdx.x; i < M; i += stride) {
-                const uint32_t d = sq.hits[i];
-                const double v = in_rec ? *(const double *)(rec + (size_t)d * S4 + 4 + 2 * af) : col[d];
-                if (grp && !((grp[(d / 1000u) >> 6] >> ((d / 1000u) & 63u)) & 1ull)) continue;
-                if (v != -1.7976931348623157e308) {          // get_num_value's "no value" marker, metric-aggs.c:106,149
-                    sum += v; mn = v < mn ? v : mn; mx = v > mx ? v : mx; cnt++;
-                }
-            }
-            // fixed-shape tree: lanes, then waves, so the f64 sum is reproducible run to run
+            for (uint32_t x = x0; x < x1 && naggs > 0; x++) {
+                const uint32_t vb = __builtin_amdgcn_readfirstlane(s_items[x].y);
+                if (vb >= nvb) continue;
+                for (int a = 0; a < naggs; a++) {
+                    if (sq.agg_type[a] == MGPU_A_CARDINALITY) continue;
+                    if (fast && !pre) continue;                  // aggregated before the sample replaced the hit list
+                    const uint32_t af = (uint32_t)sq.agg_field[a];
+                    const uint64_t *grp = fast ? sq.sh.grp_has[af] : nullptr;    // fast mode reads idnum2dbl: a missing group = no value
+                    const double *col = sq.sh.num_col[af];
+                    const bool in_rec = af < nnum_in;
+                    double sum = 0.0, mn = 1.7976931348623157e308, mx = -1.7976931348623157e308;
+                    unsigned long long cnt = 0;
+                    for (uint32_t i = vb * MG_BLOCK + threadIdx.x; i < M; i += stride) {
+                        const uint32_t d = hits[i];
+                        const double v = in_rec ? *(const double *)(rec + (size_t)d * S4 + 4 + 2 * af) : col[d];
+                        if (grp && !((grp[(d / 1000u) >> 6] >> ((d / 1000u) & 63u)) & 1ull)) continue;
+                        if (v != -1.7976931348623157e308) {          // get_num_value's "no value" marker, metric-aggs.c:106,149
+                            sum += v; mn = v < mn ? v : mn; mx = v > mx ? v : mx; cnt++;
+                        }
+                    }
+                    // fixed-shape tree: lanes, then waves, so the f64 sum is reproducible run to run
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const double s2 = __shfl_down(sum, o, 64), n2 = __shfl_down(mn, o, 64), x2 = __shfl_down(mx, o, 64);
-                const unsigned long long c2 = __shfl_down(cnt, o, 64);
-                sum += s2; mn = n2 < mn ? n2 : mn; mx = x2 > mx ? x2 : mx; cnt += c2;
-            }
-            if ((threadIdx.x & 63) == 0) { AggPart p = {sum, mn, mx, cnt}; red[threadIdx.x >> 6] = p; }
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                AggPart p = red[0];
-                for (int w2 = 1; w2 < MG_BLOCK / 64; w2++) {
-                    p.sum += red[w2].sum; p.mn = red[w2].mn < p.mn ? red[w2].mn : p.mn;
-                    p.mx = red[w2].mx > p.mx ? red[w2].mx : p.mx; p.cnt += red[w2].cnt;
+                    for (int o = 32; o > 0; o >>= 1) {
+                        const double s2 = __shfl_down(sum, o, 64), n2 = __shfl_down(mn, o, 64), x2 = __shfl_down(mx, o, 64);
+                        const unsigned long long c2 = __shfl_down(cnt, o, 64);
+                        sum += s2; mn = n2 < mn ? n2 : mn; mx = x2 > mx ? x2 : mx; cnt += c2;
+                    }
+                    if ((threadIdx.x & 63) == 0) { AggPart p = {sum, mn, mx, cnt}; red[threadIdx.x >> 6] = p; }
+                    __syncthreads();
+                    if (threadIdx.x == 0) {
+                        AggPart p = red[0];
+                        for (int w2 = 1; w2 < MG_BLOCK / 64; w2++) {
+                            p.sum += red[w2].sum; p.mn = red[w2].mn < p.mn ? red[w2].mn : p.mn;
+                            p.mx = red[w2].mx > p.mx ? red[w2].mx : p.mx; p.cnt += red[w2].cnt;
+                        }
+                        sq.agg_part[(size_t)vb * naggs + a] = p;
+                    }
+                    __syncthreads();
                 }
-                sq.agg_part[(size_t)vb * sq.num_aggs + a] = p;
             }
-            __syncthreads();
+            x0 = x1;
         }
     }
 }
