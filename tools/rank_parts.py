@@ -31,3 +31,6 @@ for m in masks:
         acc += eng.timing()["stages"]["rank"]["ms"]
     print("skip mask %2d: rank stage %.4f ms" % (m, acc / 4), flush=True)
 gpu.mgk_debug_skip(0)
+for p in preps:
+    eng.free_prepared(p)
+eng.close(); ix.close()
