@@ -1610,7 +1610,10 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
                 q.fdirect_mask |= 1u << f;
                 sj.gen_touched = q.fac_ord[f]; sj.m_ptr = q.num_hits;
                 // ... and with few hits not even the histogram: k_facet_hash counts the ordinals in LDS
-                if (use_fhash && sj.k <= MG_FHASH_MAX_K && q.fhash_njobs < 4) {
+                // (not for a squery that may be ranked on a sample: k_order files the hash jobs by the hit count BEFORE the
+                // sample replaces the hit list, the rank kernel and k_select_first look at the count AFTER it -- a sampled
+                // squery would fall between the two and nobody would count the field)
+                if (use_fhash && !q.fast_eligible && sj.k <= MG_FHASH_MAX_K && q.fhash_njobs < 4) {
                     q.fhash_mask |= 1u << f; sj.fhash = 1; q.fhash_jobs[q.fhash_njobs++] = (uint32_t)j; nfhash++;
                 }
             }

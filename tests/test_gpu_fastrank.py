@@ -90,3 +90,51 @@ def test_zero_typo_preference(n_exact, shards):
         check(ix, eng, {"q": "alphabet", "rankBy": {"price": "desc"}, "fullScanThreshold": 5000, "filter": {"flag": True}})
     finally:
         eng.close(); ix.close()
+
+
+def test_fast_rank_with_a_sparse_single_valued_facet_field(monkeypatch):
+    """A field with more values than an LDS histogram holds, one value per document, is counted straight from the rank
+    kernel -- or, for squeries of few hits, by hashing the hits' ordinals (k_facet_hash).  k_order files the hash jobs by
+    the hit count BEFORE a sample replaces the hit list; the kernels that skip their own counting for hashed squeries look
+    at the count AFTER it.  A sampled squery used to fall between the two and came back with an empty facet list (found in
+    round 3): such squeries are no hash jobs any more.  The sample's counts of a 20000-value field are ties nearly
+    everywhere, so which values are listed is the canonical choice, not the reference's (ties): the lists are
+    checked for what must hold whatever the choice -- every listed count is the EXACT number of matching documents with
+    that value (the recount, squery.c:398-408), in descending order -- and against the other counting paths."""
+    import ctypes as C
+    from marlin_amd import ffi
+    lib = ffi.load()
+    V, S = 2048, 5
+    shards = [lib.msynth_zipf(140_000, V, 20_000, S, s, 2) for s in range(2)]
+    ix = Index.from_shards({"fullScanThreshold": 5000}, shards, ["str"], ["num", "price"], ["flag"], ["cat", "hc"])
+    eng = GpuEngine(ix)
+    buf = C.create_string_buffer(16)
+
+    def word(r):
+        lib.msynth_zipf_word(V, S, r, buf)
+        return buf.value.decode()
+    try:
+        for q in ({"q": word(0), "rankBy": {"num": "desc"}, "maxFacetResults": 10},
+                  {"q": word(1) + " " + word(2)[:3], "rankBy": {"num": "asc"}, "maxFacetResults": 10},
+                  {"q": "", "rankBy": {"num": "desc"}, "maxFacetResults": 5}):
+            pq = ix.query(q)
+            g = eng.search(pq, capture=1)
+            o = orc_py.search(ix, pq, flags=1)
+            assert not g["fullScan"] and not o["fullScan"] and g["totalHits"] == o["totalHits"], q
+            assert g["facets"]["cat"] == o["facets"]["cat"], q          # 64 values: the list covers them all, no tie decides
+            hc = g["facets"]["hc"]
+            assert len(hc) == q["maxFacetResults"], (q, hc)
+            assert [e["count"] for e in hc] == sorted((e["count"] for e in hc), reverse=True), q
+            # per shard (the merged count of a value adds only what the shards LISTED, query.c:61-91)
+            for s in range(ix.num_shards):
+                lst = g["_shards"][s]["facets"][1]
+                assert len(lst) == 2 * q["maxFacetResults"], (q, s)
+                for fid, cnt in lst[:3]:
+                    exact = eng.search(ix.query({"q": q["q"], "filter": {"hc": ix.facet_string(s, fid)}, "fullScan": True, "hitsPerPage": 0}), capture=1)
+                    assert exact["_shards"][s]["num_hits"] == cnt, (q, s, fid)
+            for switch in ("MGPU_NO_HASH_FACETS", "MGPU_NO_DIRECT_FACETS", "MGPU_NO_FUSED_FKEYS"):
+                monkeypatch.setenv(switch, "1")
+                assert eng.search(pq)["facets"] == g["facets"], (q, switch)
+                monkeypatch.delenv(switch)
+    finally:
+        eng.close(); ix.close()
