@@ -18,3 +18,10 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("seed", [3, 2024])
 def test_generated_queries_match_the_oracle(seed):
     assert fuzz_parity.main(150, seed) == 0
+
+
+def test_generated_queries_in_the_default_mode():
+    """the as-shipped mode: shards above fullScanThreshold hits are ranked on a sample (tools/fuzz_default_mode.py)"""
+    import fuzz_default_mode
+    bad, n, fast = fuzz_default_mode.main(120, 7)
+    assert bad == 0 and n > 80 and fast > 20
