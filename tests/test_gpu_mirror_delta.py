@@ -140,3 +140,33 @@ def test_no_headroom_falls_back_to_a_rebuild(monkeypatch):
         assert n > 50 and bad == 0
     finally:
         eng.close(); ix.close(); ix2.close()
+
+
+def test_delta_edge_cases():
+    """nothing new (the same shards again), a single new document, and a shard that was EMPTY before the write"""
+    rng = random.Random(13)
+    docs = make_docs(rng, 1200)
+    ix0 = Index(SETTINGS, num_shards=3).add_documents(docs[:2])          # shard 2 holds no document yet
+    eng = GpuEngine(ix0)
+    keep = [ix0]
+    try:
+        for cut in (2, 3, 1200):
+            ix = Index(SETTINGS, num_shards=3).add_documents(docs[:cut])
+            keep.append(ix)
+            assert eng.apply_index(ix) == ["delta"] * 3, cut
+            assert [eng.lib.mgpu_shard_max_docid(eng.lib.mmirror_gpu(m)) for m in eng.mirrors] == [ix.max_docid(s) for s in range(3)]
+            n, bad = fz.run(ix, eng, queries(rng, 50), "edge@%d" % cut)
+            assert bad == 0 and n > 25
+        same = Index(SETTINGS, num_shards=3).add_documents(docs)
+        keep.append(same)
+        assert eng.apply_index(same) == ["delta"] * 3                     # an empty delta
+        n, bad = fz.run(same, eng, queries(rng, 50), "again")
+        assert bad == 0 and n > 25
+        # a write that is not an append (a document gone) is refused by the delta path and rebuilt
+        fewer = Index(SETTINGS, num_shards=3).add_documents(docs[:600])
+        keep.append(fewer)
+        assert eng.lib.mmirror_apply_shard(eng.mirrors[0], fewer.shards[0]) == -5
+    finally:
+        eng.close()
+        for i in keep:
+            i.close()
