@@ -255,7 +255,9 @@ int mgpu_posting_op(mgpu_ctx_t *c, mgpu_shard_t *s, int op, uint32_t pid_a, uint
 
 
 /* mgpu_posting_op for callers that cannot allocate.  No counterpart in the reference: it exists for callers
- * that may not call hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid it.
+ * that may not call hipMalloc -- tight serving loops, harnesses that forbid it, code that runs while another stream
+ * of the process is under HIP graph capture (the call itself waits for its stream and hands its results to the
+ * host, so it is not something to capture; it also refuses a context with a batch in flight).
  * Same arguments, results and error codes as mgpu_posting_op; its scratch (two operand rows, the result row, the
  * cardinality word) is a static device array of 3 * MGPU_NOALLOC_MAX_DOCS / 8 + 256 bytes (6 MiB + 256 B) that
  * every GPU the library runs on holds until the process ends.  Shards with more than MGPU_NOALLOC_MAX_DOCS docids

@@ -786,7 +786,7 @@ struct Arena {
 
 struct mgpu_ctx {
     int device;
-    hipStream_t stream;
+    hipStream_t stream = nullptr;
     Arena arena;
     char *pin = nullptr; size_t pin_cap = 0;          // pinned staging for uploads
     char *pin_out = nullptr; size_t pin_out_cap = 0;  // pinned buffer for results
@@ -805,7 +805,7 @@ struct mgpu_ctx {
     uint32_t *lk_count = nullptr;
     char *hl_buf = nullptr; size_t hl_cap = 0;                // highlight matcher (mgpu_highlight_match): inputs + result, grown on demand
     uint2 *lk_cand = nullptr; uint32_t lk_cand_cap = 0;      // (job, word) pairs the signature filter let through
-    hipEvent_t ev[MGPU_NUM_STAGES + 1];
+    hipEvent_t ev[MGPU_NUM_STAGES + 1] = {};
     int profiling;
     float stage_ms[MGPU_NUM_STAGES];
     float total_ms;
@@ -813,12 +813,10 @@ struct mgpu_ctx {
     uint64_t stage_bytes[MGPU_NUM_STAGES];
 };
 
-extern "C" int mgpu_ctx_create(int device, uint64_t scratch_bytes, mgpu_ctx_t **out) {
-    if (!out) return fail(MGPU_E_ARG, "null argument");
-    HIPCHK(hipSetDevice(device));
-    mgpu_ctx *c = new mgpu_ctx();
-    c->device = device; c->profiling = 0; c->total_ms = 0;
-    memset(c->stage_ms, 0, sizeof(c->stage_ms)); memset(c->stage_bytes, 0, sizeof(c->stage_bytes));
+static void pending_free(struct Pending *p);
+extern "C" void mgpu_ctx_destroy(mgpu_ctx_t *c);
+// (a failure part-way leaves nothing behind: the half-built context goes through mgpu_ctx_destroy)
+static int ctx_create_steps(mgpu_ctx *c, int device, uint64_t scratch_bytes) {
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     if (!scratch_bytes) scratch_bytes = 64ull << 20;
     c->pool_cap = scratch_bytes / 8;
@@ -827,7 +825,6 @@ extern "C" int mgpu_ctx_create(int device, uint64_t scratch_bytes, mgpu_ctx_t **
     for (int i = 0; i <= MGPU_NUM_STAGES; i++) HIPCHK(hipEventCreate(&c->ev[i]));
     // set-up of the allocation-free entry point: this device's address of the static scratch array (each GPU has
     // its own copy at its own address) and a pinned bounce buffer for its results
-    if (device < 0 || device >= NA_MAX_DEVICES) return fail(MGPU_E_LIMIT, "device index above 63");
     {
         static std::mutex mu;
         std::lock_guard<std::mutex> lk(mu);
@@ -839,29 +836,40 @@ extern "C" int mgpu_ctx_create(int device, uint64_t scratch_bytes, mgpu_ctx_t **
     }
     c->na_scratch = g_na_ptr[device];
     HIPCHK(hipHostMalloc((void **)&c->na_pin, NA_ROW_BYTES + 256, hipHostMallocDefault));
+    return MGPU_OK;
+}
+extern "C" int mgpu_ctx_create(int device, uint64_t scratch_bytes, mgpu_ctx_t **out) {
+    if (!out) return fail(MGPU_E_ARG, "null argument");
+    if (device < 0 || device >= NA_MAX_DEVICES) return fail(MGPU_E_LIMIT, "device index above 63");
+    HIPCHK(hipSetDevice(device));
+    mgpu_ctx *c = new mgpu_ctx();
+    c->device = device; c->profiling = 0; c->total_ms = 0;
+    memset(c->stage_ms, 0, sizeof(c->stage_ms)); memset(c->stage_bytes, 0, sizeof(c->stage_bytes));
+    const int rc = ctx_create_steps(c, device, scratch_bytes);
+    if (rc != MGPU_OK) { mgpu_ctx_destroy(c); return rc; }          // (the thread's error text is the failing step's)
     *out = c;
     return MGPU_OK;
 }
 
-static void pending_free(struct Pending *p);
 extern "C" void mgpu_ctx_destroy(mgpu_ctx_t *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     pending_free(c->pend);
     if (c->arena.dev) (void)hipFree(c->arena.dev);
     if (c->cln.dev) (void)hipFree(c->cln.dev);
     if (c->pin) (void)hipHostFree(c->pin);
     if (c->pin_out) (void)hipHostFree(c->pin_out);
     if (c->na_pin) (void)hipHostFree(c->na_pin);
-    (void)hipFree(c->pool); (void)hipFree(c->pool_used);
+    if (c->pool) (void)hipFree(c->pool);
+    if (c->pool_used) (void)hipFree(c->pool_used);
     if (c->lk_in) (void)hipFree(c->lk_in);
     if (c->lk_hits) (void)hipFree(c->lk_hits);
     if (c->lk_count) (void)hipFree(c->lk_count);
     if (c->lk_cand) (void)hipFree(c->lk_cand);
     if (c->hl_buf) (void)hipFree(c->hl_buf);
-    for (int i = 0; i <= MGPU_NUM_STAGES; i++) (void)hipEventDestroy(c->ev[i]);
-    (void)hipStreamDestroy(c->stream);
+    for (int i = 0; i <= MGPU_NUM_STAGES; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -1934,8 +1942,9 @@ extern "C" int mgpu_posting_op(mgpu_ctx_t *c, mgpu_shard_t *s, int op, uint32_t 
     return MGPU_OK;
 }
 
-// The same operation for callers that cannot allocate (HIP graph capture around it, serving loops and harnesses
-// that forbid hipMalloc).  No hipMalloc / hipFree / hipHostMalloc and no host heap use in here: the operand rows,
+// The same operation for callers that cannot allocate (serving loops and harnesses that forbid hipMalloc, code that
+// runs while a capture is open elsewhere in the process; the call waits for its own stream, so it is not capturable
+// itself).  No hipMalloc / hipFree / hipHostMalloc and no host heap use in here: the operand rows,
 // the result row and the cardinality word live in this device's copy of g_noalloc_scratch (address looked up at
 // mgpu_ctx_create), sparse postings are scattered by a kernel that takes the list as its arguments (no item table
 // to upload), and results come back through the context's pinned bounce buffer.  Every call on a GPU shares that
@@ -1953,8 +1962,9 @@ extern "C" int mgpu_posting_op_noalloc(mgpu_ctx_t *c, mgpu_shard_t *s, int op, u
         return fail(MGPU_E_LIMIT, "mgpu_posting_op_noalloc: shard has more than MGPU_NOALLOC_MAX_DOCS docids (static scratch holds three rows of that size)");
     if (out_words && nwords < sd.W) return fail(MGPU_E_ARG, "output buffer too small");
     if (!c->na_scratch || !c->na_pin) return fail(MGPU_E_HIP, "context has no static scratch (mgpu_ctx_create did not finish)");
+    if (c->pend && c->pend->active) return fail(MGPU_E_ARG, "a batch is in flight on this context");
     HIPCHK(hipSetDevice(c->device));
-    char *S = c->na_scratch;                                    // the device address, never the array's name
+    char *S = c->na_scratch;                                   // the device address, never the array's name
     u64 *ra = (u64 *)S, *rb = (u64 *)(S + NA_ROW_BYTES), *ro = (u64 *)(S + 2 * NA_ROW_BYTES);
     unsigned long long *dcard = (unsigned long long *)(S + 3 * NA_ROW_BYTES);
     hipStream_t st = c->stream;
