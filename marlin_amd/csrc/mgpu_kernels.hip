@@ -138,10 +138,17 @@ __device__ __forceinline__ void emit_bits(u64 v, uint32_t base, uint32_t *hits, 
         hits[off++] = base + (uint32_t)b;
     }
 }
-__global__ __launch_bounds__(MG_BLOCK) void k_formula(const SqDev *sqs, const uint32_t *blob) {
+#define MG_FORMULA_RUN 4             // consecutive windows of a squery that one workgroup takes when the launch is large
+// (five waves per SIMD is what the 31 KB of LDS allow; unbounded, the compiler takes 103 VGPRs for the loop and leaves four)
+__global__ __launch_bounds__(MG_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_formula(const SqDev *sqs, const uint32_t *blob, uint32_t run) {
     const SqDev *sp = &sqs[blockIdx.y];
     const uint32_t nblk = sp->nblk;                                  // 256-word blocks of the row
-    if (blockIdx.x * (MG_FORMULA_WORDS / MG_WORDS_PER_BLOCK) >= nblk) return;
+    const uint32_t nwin = (nblk + MG_FORMULA_WORDS / MG_WORDS_PER_BLOCK - 1) / (MG_FORMULA_WORDS / MG_WORDS_PER_BLOCK);
+    // A workgroup takes a run of consecutive windows: the descriptor, the plan and the descriptors of the first 256
+    // lists are fetched once per run, and the next window's slice bounds travel behind the current window's emit.
+    const uint32_t win_first = blockIdx.x * run;
+    if (win_first >= nwin) return;
+    const uint32_t win_end = win_first + run < nwin ? win_first + run : nwin;
     // descriptor fields in one burst
     const uint32_t Wp = sp->sh.Wp;
     const int nt = sp->num_terms, nf = sp->num_fops, empty = sp->empty;
@@ -160,7 +167,6 @@ __global__ __launch_bounds__(MG_BLOCK) void k_formula(const SqDev *sqs, const ui
     __shared__ uint32_t s_pre[MG_BLOCK], s_src[MG_BLOCK], s_trm[MG_BLOCK], s_scan[8];
     const uint32_t *plan = blob + plan_off;
     const bool in_lds = plan_len <= MG_PLAN_LDS;
-    const uint32_t win = blockIdx.x;
     // first term group's lists: descriptor and window range of list (lb0 + lane) go out now, together
     // with the plan, so that only the element loads remain behind the first barrier
     const int tg0 = nt < MG_TILE_TERMS ? nt : MG_TILE_TERMS;
@@ -170,19 +176,20 @@ __global__ __launch_bounds__(MG_BLOCK) void k_formula(const SqDev *sqs, const ui
     if (!empty && lb0 + threadIdx.x < le0) {
         d0 = sl[lb0 + threadIdx.x];
         r0e = d0.z;
-        if (d0.w != 0xFFFFFFFFu) { r0s = post_win[d0.w + win]; r0e = post_win[d0.w + win + 1]; }
+        if (d0.w != 0xFFFFFFFFu) { r0s = post_win[d0.w + win_first]; r0e = post_win[d0.w + win_first + 1]; }
     }
     if (in_lds) {
         for (uint32_t i = threadIdx.x; i < plan_len; i += MG_BLOCK) s_plan[i] = plan[i];
         __syncthreads();
     }
+    auto word = [&](uint32_t i) -> uint32_t { return in_lds ? s_plan[i] : plan[i]; };
+    for (uint32_t win = win_first; win < win_end; win++) {
     const uint32_t base = win * MG_FORMULA_WORDS;
     const uint32_t w0 = base + 2 * threadIdx.x;
     const bool in0 = w0 < Wp;
     W2 v = {0, 0};
     if (!empty) {                                 // uniform: the tile builder below synchronises the workgroup
         int tcur = 0;
-        auto word = [&](uint32_t i) -> uint32_t { return in_lds ? s_plan[i] : plan[i]; };
         auto row_of = [&](uint32_t e) -> const u64 * {
             return ((int32_t)e >= 0) ? dense + (size_t)e * Wp : rows + (size_t)(~e) * Wp;
         };
@@ -287,6 +294,9 @@ __global__ __launch_bounds__(MG_BLOCK) void k_formula(const SqDev *sqs, const ui
         }
         if (!in0) { v.a = 0; v.b = 0; }          // words past the row (the last window of a shard) hold nothing
     }
+    // the next window's slice of this lane's list (its start is this window's end): in flight behind the emit
+    uint32_t r0e_next = r0e;
+    if (win + 1 < win_end && d0.w != 0xFFFFFFFFu) r0e_next = post_win[d0.w + win + 2];
     // (the dense docid_map is only written when somebody asked for it: parity captures)
     if (docid_map && in0) *(ulonglong2 *)(docid_map + w0) = make_ulonglong2(v.a, v.b);
     // bmap_iterate fused in (bmap.c:370-374, cont.c:590-610): the window's hits go straight to the raw hit list.
@@ -309,6 +319,8 @@ __global__ __launch_bounds__(MG_BLOCK) void k_formula(const SqDev *sqs, const ui
     if (cnt && hits_raw && rbase != 0xFFFFFFFFu) {
         off += rbase;
         emit_bits(v.a, w0 << 6, hits_raw, off); emit_bits(v.b, (w0 + 1) << 6, hits_raw, off);
+    }
+    if (d0.w != 0xFFFFFFFFu) { r0s = r0e; r0e = r0e_next; }
     }
 }
 
@@ -2720,7 +2732,12 @@ static uint32_t worklist_grid(uint32_t tile_cap) {
 }
 void mgk_formula(hipStream_t st, const SqDev *sqs, const uint32_t *blob, uint32_t max_nblk, uint32_t nsq,
                  uint2 *tile_list, uint32_t *tile_count, uint32_t tile_cap, uint32_t *fh_list, uint32_t *fh_count, uint32_t fh_cap) {
-    hipLaunchKernelGGL(k_formula, dim3((max_nblk + 1) / 2, nsq), dim3(MG_BLOCK), 0, st, sqs, blob);
+    // runs of windows pay when the launch fills the chip several times over (-12 % on a 1024-squery batch); a lone query's
+    // few hundred windows are better off side by side
+    const uint32_t max_nwin = (max_nblk + 1) / 2;
+    static const int forced = getenv("MGPU_FORMULA_RUN") ? atoi(getenv("MGPU_FORMULA_RUN")) : 0;     // tests: runs on small shards
+    const uint32_t run = forced > 0 ? (uint32_t)forced : (uint64_t)max_nwin * nsq >= 8192 ? MG_FORMULA_RUN : 1u;
+    hipLaunchKernelGGL(k_formula, dim3((max_nwin + run - 1) / run, nsq), dim3(MG_BLOCK), 0, st, sqs, blob, run);
     hipLaunchKernelGGL(k_order, dim3(nsq), dim3(MG_BLOCK), 0, st, sqs, tile_list, tile_count, fh_list, fh_count, fh_cap);
     hipLaunchKernelGGL(k_order_copy, dim3(worklist_grid(tile_cap)), dim3(MG_BLOCK), 0, st, sqs, tile_list, tile_count);
 }

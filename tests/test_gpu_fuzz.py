@@ -25,3 +25,16 @@ def test_generated_queries_in_the_default_mode():
     import fuzz_default_mode
     bad, n, fast = fuzz_default_mode.main(120, 7)
     assert bad == 0 and n > 80 and fast > 20
+
+
+@pytest.mark.parametrize("run", [2, 4])
+def test_generated_queries_with_formula_workgroups_over_runs_of_windows(run):
+    """k_formula takes runs of consecutive windows per workgroup only when a launch is large (mgk_formula); here the run
+    length is forced, so that the small corpora of the generator (three windows per shard: a full run and a ragged one
+    for run = 2) go through that loop as well.  A process of its own: the library reads the variable once."""
+    import subprocess
+    env = dict(os.environ, MGPU_FORMULA_RUN=str(run))
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py")
+    r = subprocess.run([sys.executable, tool, "100", str(50 + run)], env=env, capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "0 + 0 + 0 mismatches" in r.stdout
