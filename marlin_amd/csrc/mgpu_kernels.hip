@@ -1867,7 +1867,7 @@ __device__ __forceinline__ void select_solo(const SelJob &job, const SelOut &out
 // Rank of this lane's key (h, l, i) among the NT lanes' keys when it is one of the k smallest, else some number >= k.
 // Keys must differ between lanes.  Two levels: every wave ranks its 64 keys with lane broadcasts (no LDS), the min(k, 64)
 // smallest of each wave -- the only ones that can be among the k smallest overall -- meet in LDS and are ranked against
-// each other.  b_hi / b_lo / b_ix: (NT / 64) * min(k, 64) entries each.  Contains one barrier.
+// each other.  b_hi / b_lo / b_ix: (NT / 64) * min(k, 64) entries each.  Contains three barriers.
 template <int NT>
 __device__ __forceinline__ uint32_t lane_rank_below_k(u64 h, u64 l, uint32_t i, uint32_t k, u64 *b_hi, u64 *b_lo, uint32_t *b_ix) {
     const uint32_t wave = threadIdx.x >> 6;
@@ -1881,11 +1881,19 @@ __device__ __forceinline__ uint32_t lane_rank_below_k(u64 h, u64 l, uint32_t i, 
     const uint32_t kk = k < 64 ? k : 64;
     if (lr < kk) { b_hi[wave * kk + lr] = h; b_lo[wave * kk + lr] = l; b_ix[wave * kk + lr] = i; }
     __syncthreads();
-    if (lr >= kk) return k;
+    // Candidate c is ranked by thread c: the (NT / 64) * kk candidates fill whole waves, where their owners are kk lanes
+    // of EVERY wave (all NT / 64 waves would walk the list); the rank goes back to the owner through b_ix.
+    const uint32_t nc = (NT / 64) * kk;
     uint32_t r = 0;
+    if (threadIdx.x < nc) {
+        const u64 ch = b_hi[threadIdx.x], cl = b_lo[threadIdx.x]; const uint32_t ci = b_ix[threadIdx.x];
 #pragma unroll 8
-    for (uint32_t x = 0; x < (NT / 64) * kk; x++) r += key_lt(b_hi[x], b_lo[x], b_ix[x], h, l, i) ? 1u : 0u;
-    return r;
+        for (uint32_t x = 0; x < nc; x++) r += key_lt(b_hi[x], b_lo[x], b_ix[x], ch, cl, ci) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (threadIdx.x < nc) b_ix[threadIdx.x] = r;
+    __syncthreads();
+    return lr < kk ? b_ix[wave * kk + lr] : k;
 }
 
 template <int NT>
