@@ -104,8 +104,9 @@ uint64_t mgpu_shard_bytes(const mgpu_shard_t *s);
  * device (old run + new docids per posting, k_merge_postings) and its window index recomputed (k_build_winidx), dense rows
  * take their new bits in place (k_scatter), records / docwords / positions / columns / facet ordinals of the new documents
  * are appended into the headroom the mirror was built with (MGPU_MIRROR_HEADROOM, default 12.5 % + 4096 documents).
- * MGPU_E_LIMIT = no room left (nothing was changed): rebuild the mirror with mgpu_shard_create.  The caller makes sure no
- * batch that names this shard is in flight during the call.  Deleted or replaced documents are not a delta: rebuild. */
+ * MGPU_E_LIMIT = no room left, MGPU_E_ARG = not a valid delta (nothing was changed either way): rebuild the mirror with
+ * mgpu_shard_create.  Any other error (a device failure part-way) leaves the mirror half-updated: destroy it and rebuild.
+ * The caller makes sure no batch that names this shard is in flight during the call.  Deleted or replaced documents are not a delta: rebuild. */
 typedef struct mgpu_shard_delta {
     uint32_t max_docid;                 /* after the write; the new documents are old max_docid + 1 .. max_docid */
     uint32_t num_postings;              /* pids of the scheme after the write: 0..num_postings-1 */

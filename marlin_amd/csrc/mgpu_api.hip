@@ -582,9 +582,12 @@ extern "C" int mgpu_shard_apply_delta(mgpu_shard_t *s, const mgpu_shard_delta_t 
     if (d->num_postings < sd.num_postings) return fail(MGPU_E_ARG, "a delta cannot take postings away");
     const uint32_t nd = N1 - N0, P0 = sd.num_postings, P1 = d->num_postings;
     if (nd && (!d->dd_off || !d->dd)) return fail(MGPU_E_ARG, "blobs of the new documents missing");
+    for (int i = 0; i < sd.num_numbers; i++) if (d->np_n[i] && !d->np_doc[i]) return fail(MGPU_E_ARG, "num_dbi order missing");
     HIPCHK(hipSetDevice(s->device));
     int rc;
-    // ---- 1. everything that can fail is prepared before the mirror is touched
+    // ---- 1. what can be checked is checked before the mirror is touched: MGPU_E_ARG / MGPU_E_LIMIT leave it as it was.
+    // A device failure further down (MGPU_E_HIP: out of memory, a lost device) may leave it half-updated -- the rows
+    // have their new bits before the tables are swapped: the caller destroys such a mirror and builds a new one.
     // pid scheme: every old posting exactly once, in order
     std::vector<uint32_t> old_pid(P1);
     {
@@ -772,7 +775,6 @@ extern "C" int mgpu_shard_apply_delta(mgpu_shard_t *s, const mgpu_shard_delta_t 
     for (int i = 0; i < sd.num_numbers; i++) {
         const uint32_t *old_np = sd.np_doc[i]; const uint64_t *old_grp = sd.grp_has[i];
         const uint64_t old_n = s->np_n[i];
-        if (d->np_n[i] && !d->np_doc[i]) return fail(MGPU_E_ARG, "num_dbi order missing");
         if ((rc = set_num_order(s, i, d->np_doc[i], d->np_n[i], &sd.np_doc[i], &sd.grp_has[i]))) return rc;
         drop_alloc(s, old_np, (size_t)std::max<uint64_t>(old_n, 1) * 4); drop_alloc(s, old_grp, 0);
     }

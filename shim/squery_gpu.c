@@ -651,7 +651,9 @@ int mgpu_shim_refresh_shard(struct shard *s) {
     if (applied) { mshard_free(old_src); return 0; }
     mshard_free(src);
     if (!m) return 1;
-    if (rc != MGPU_E_LIMIT && rc != MGPU_E_UNSUPPORTED) { M_ERR("gpu squery: delta for shard %d: %s", s->shard_id, mgpu_last_error()); return rc; }
+    /* no headroom left / not an append are the expected reasons; after any other failure the live mirror may be
+     * half-updated (include/marlin_gpu.h), so it is replaced all the same */
+    if (rc != MGPU_E_LIMIT && rc != MGPU_E_UNSUPPORTED) M_ERR("gpu squery: delta for shard %d failed (%d: %s): rebuilding the mirror", s->shard_id, rc, mgpu_last_error());
     rc = mgpu_shim_attach_shard(s, device);
     return rc ? rc : 2;
 }
