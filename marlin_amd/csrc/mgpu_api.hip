@@ -2120,7 +2120,7 @@ extern "C" int mgpu_lookup_terms(mgpu_ctx_t *c, const mgpu_term_lookup_t *lookup
     }
     if (total) {
         mgpu_term_hit_t *h = (mgpu_term_hit_t *)malloc((size_t)total * sizeof(mgpu_term_hit_t));
-        if (!h) return fail(MGPU_E_ARG, "out of host memory");
+        if (!h) return fail(MGPU_E_LIMIT, "out of host memory");
         hipError_t e = hipMemcpy(h, c->lk_hits, (size_t)total * 12, hipMemcpyDeviceToHost);
         if (e != hipSuccess) { free(h); return fail(MGPU_E_HIP, hipGetErrorString(e)); }
         *hits = h;

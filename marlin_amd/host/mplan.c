@@ -603,10 +603,11 @@ static int resolve_batch_impl(mgpu_ctx_t *ctx, mmirror_t *const *mirrors, int nu
     if (!r || !tr || !have) { free(r); free(tr); free(have); return MGPU_E_LIMIT; }
     r->n = n; r->nq = nq; r->num_shards = num_shards; r->mirrors = mirrors;
     r->queries = calloc((size_t)(nq ? nq : 1), sizeof(*r->queries));
-    memcpy(r->queries, queries, (size_t)nq * sizeof(*r->queries));
     r->twid = calloc((size_t)(n ? n : 1) * M_MAX_QTERMS, sizeof(uint32_t));
     r->t_off = calloc((size_t)(n ? n : 1) * M_MAX_QTERMS + 1, sizeof(uint32_t));
     r->exact = calloc((size_t)(n ? n : 1) * M_MAX_QWORDS, sizeof(uint32_t));
+    if (!r->queries || !r->twid || !r->t_off || !r->exact) { msq_resolved_free(r); free(tr); free(have); return MGPU_E_LIMIT; }
+    memcpy(r->queries, queries, (size_t)nq * sizeof(*r->queries));
     int rc = 0;
     static int trace = -1;
     if (trace < 0) trace = getenv("MSQ_PREP_TRACE") != NULL;
@@ -627,8 +628,9 @@ static int resolve_batch_impl(mgpu_ctx_t *ctx, mmirror_t *const *mirrors, int nu
         mgpu_term_lookup_t *lk = malloc(sizeof(*lk) * (nl ? nl : 1));
         uint32_t *slot = malloc(sizeof(uint32_t) * (nl ? nl : 1));          /* lookup -> index into tr[] */
         dv_slot_of = malloc(sizeof(uint32_t) * (nl ? nl : 1));
+        if (!lk || !slot || !dv_slot_of) rc = MGPU_E_LIMIT;
         nl = 0;
-        for (int i = 0; i < n; i++) {
+        for (int i = 0; i < n && !rc; i++) {
             const m_query_t *q = queries[i / num_shards];
             if (!mirrors[i % num_shards]->gd) continue;
             for (int t = 0; t < q->num_terms; t++) {
@@ -643,8 +645,7 @@ static int resolve_batch_impl(mgpu_ctx_t *ctx, mmirror_t *const *mirrors, int nu
         /* The hits of the device ({lookup, wid, distance}, any order) become one (wid, distance) run per lookup: counted
          * per lookup, placed, then each short run ordered by wid with the least distance kept (add_wordid_to_result,
          * dtrie.c:633-640) -- no hash map and no malloc per term.  At most 65535 lookups per call. */
-        dv_off = calloc(nl + 2, sizeof(uint32_t));
-        if (!dv_off) rc = MGPU_E_LIMIT;
+        if (!rc && !(dv_off = calloc(nl + 2, sizeof(uint32_t)))) rc = MGPU_E_LIMIT;
         /* the host's share (exact descents, twid terms: every slot without `have`) runs in worker threads WHILE the
          * device scores the typo walks */
         if (!rc) {
@@ -708,8 +709,10 @@ static int resolve_batch_impl(mgpu_ctx_t *ctx, mmirror_t *const *mirrors, int nu
             }
             if (nthreads == 1) resolve_worker(&jobs[0]);
             else {
-                for (int t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, resolve_worker, &jobs[t]);
-                for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+                int made = 0;
+                while (made < nthreads && !pthread_create(&th[made], NULL, resolve_worker, &jobs[made])) made++;
+                for (int t = made; t < nthreads; t++) resolve_worker(&jobs[t]);          /* no thread to be had: here and now */
+                for (int t = 0; t < made; t++) pthread_join(th[t], NULL);
             }
         }
         /* flatten: host results from their maps, device results from their runs (lookups were made in slot order) */
@@ -718,8 +721,9 @@ static int resolve_batch_impl(mgpu_ctx_t *ctx, mmirror_t *const *mirrors, int nu
         if (tot >= 0xFFFFFFFFull) rc = MGPU_E_LIMIT;
         else {
             r->wid = malloc(sizeof(uint32_t) * (tot ? tot : 1)); r->dist = malloc(tot ? tot : 1);
+            if (!r->wid || !r->dist) rc = MGPU_E_LIMIT;
             size_t at = 0, l = 0;
-            for (size_t k = 0; k < (size_t)n * M_MAX_QTERMS; k++) {
+            for (size_t k = 0; k < (size_t)n * M_MAX_QTERMS && !rc; k++) {
                 r->t_off[k] = (uint32_t)at;
                 r->twid[k] = tr[k].twid;
                 if (l < nl && dv_slot_of && dv_slot_of[l] == k) {
@@ -731,8 +735,7 @@ static int resolve_batch_impl(mgpu_ctx_t *ctx, mmirror_t *const *mirrors, int nu
                 const m_u32map_t *mp = &tr[k].wordids;
                 for (uint32_t x = 0; x < mp->cap; x++) if (mp->keys[x]) { r->wid[at] = mp->keys[x]; r->dist[at] = (uint8_t)mp->vals[x]; at++; }
             }
-            r->t_off[(size_t)n * M_MAX_QTERMS] = (uint32_t)at;
-            r->nwd = at;
+            if (!rc) { r->t_off[(size_t)n * M_MAX_QTERMS] = (uint32_t)at; r->nwd = at; }
         }
     }
     if (trace) {
