@@ -653,7 +653,10 @@ int mgpu_shim_refresh_shard(struct shard *s) {
     if (!m) return 1;
     /* no headroom left / not an append are the expected reasons; after any other failure the live mirror may be
      * half-updated (include/marlin_gpu.h), so it is replaced all the same */
-    if (rc != MGPU_E_LIMIT && rc != MGPU_E_UNSUPPORTED) M_ERR("gpu squery: delta for shard %d failed (%d: %s): rebuilding the mirror", s->shard_id, rc, mgpu_last_error());
+    if (rc != MGPU_E_LIMIT && rc != MGPU_E_UNSUPPORTED) {
+        M_ERR("gpu squery: delta for shard %d failed (%d: %s): rebuilding the mirror", s->shard_id, rc, mgpu_last_error());
+        mgpu_shim_detach_shard(s);             /* queries fail (and say so) until the new mirror is in, rather than read this one */
+    }
     rc = mgpu_shim_attach_shard(s, device);
     return rc ? rc : 2;
 }
