@@ -1580,6 +1580,12 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
     const bool fuse_fk = max_fac_nord <= MG_SEL_MID_KEYS && max_fac_k <= MG_SEL_SOLO_K && !getenv("MGPU_NO_FUSED_FKEYS");
     const bool use_fdirect = !getenv("MGPU_NO_DIRECT_FACETS");
     const bool use_fhash = !getenv("MGPU_NO_HASH_FACETS");
+    // The bound is on hit_cap, which the host computes from posting cardinalities and is often far above the hit count: a
+    // squery above it falls back to per-hit returning atomics in k_docproc and, for a 100k-value field, to lists the wide
+    // select launches take -- although it may have a few thousand hits.  MGPU_FDIRECT_CAP lifts the bound (the kernels
+    // cope: tests/test_gpu_fastrank.py); measured on the bench stream, facets+aggs 0.083 -> 0.036 ms but select 0.37 -> 0.43
+    // (lists of one key per HIT instead of one per touched bin for the squeries of 50-100k hits), so the default stays.
+    const uint32_t fdirect_max_cap = getenv("MGPU_FDIRECT_CAP") ? (uint32_t)strtoul(getenv("MGPU_FDIRECT_CAP"), nullptr, 10) : MG_FDIRECT_MAX_CAP;
     uint32_t nfhash = 0;
     seljobs.resize(seloff.size()); selouts.resize(seloff.size());
     for (size_t j = 0; j < seloff.size(); j++) {
@@ -1616,7 +1622,7 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
             bool card_on_f = false;
             for (int a = 0; a < q.num_aggs; a++) card_on_f |= q.agg_type[a] == MGPU_A_CARDINALITY && q.agg_field[a] == f;
             if (fuse_fk && use_fdirect && q.fac_in_rank && ((shards[jf.sq]->fac_single >> f) & 1u) && q.sh.fa_nord[f] > MG_LDS_HIST &&
-                !card_on_f && q.hit_cap <= MG_SEL_MID_KEYS) {
+                !card_on_f && q.hit_cap <= fdirect_max_cap) {
                 q.fdirect_mask |= 1u << f;
                 sj.gen_touched = q.fac_ord[f]; sj.m_ptr = q.num_hits;
                 // ... and with few hits not even the histogram: k_facet_hash counts the ordinals in LDS

@@ -2334,7 +2334,9 @@ __global__ __launch_bounds__(MG_BLOCK) void k_select_first(const SelJob *jobs, c
         select_solo<MG_BLOCK>(job, out, M, mhi, mlo, midx, hist, s_scan, s_pcur, s_runs, s_misc, s_fhi, s_flo, s_fix, s_fcnt, s_red);
         return;
     }
-    if (M <= SEL_MID_KEYS && job.k <= MG_SEL_SOLO_K) {    // same selection by a 1024-thread workgroup of k_select_mid
+    // same selection by a 1024-thread workgroup of k_select_mid (a list whose keys are derived has no other place to go:
+    // the wide launches read keys, they do not make them)
+    if ((M <= SEL_MID_KEYS || job.gen_touched) && job.k <= MG_SEL_SOLO_K) {
         if (threadIdx.x == 0) L.mid[atomicAdd(L.nmid, 1u)] = ji;
         return;
     }

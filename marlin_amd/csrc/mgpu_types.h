@@ -100,6 +100,7 @@ struct SelJob {                      // one top-k selection (rank keys of a sque
 #define MG_FAC_NONE   0xFFFFFFFFu     // fac_ord: the document has no value in the field
 #define MG_FAC_LOOKUP 0xFFFFFFFEu     // fac_ord: several values, or not staged: k_docproc reads the record / CSR itself
 #define MG_SEL_MID_KEYS 131072u      // longest fresh list one 1024-thread workgroup selects (k_select_mid)
+#define MG_FDIRECT_MAX_CAP MG_SEL_MID_KEYS // largest hit bound (SqDev::hit_cap) of a squery whose sparse single-valued field is counted from the rank kernel
 #define MG_SEL_SOLO_K 256u           // largest k of the one-workgroup selections
 // ctl words
 enum { SEL_NCAND, SEL_KREM, SEL_NWIN, SEL_DONE, SEL_TICKET, SEL_NEXT, SEL_BITPOS, SEL_PASS, SEL_WORDS = 16 };

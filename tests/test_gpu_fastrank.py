@@ -138,3 +138,43 @@ def test_fast_rank_with_a_sparse_single_valued_facet_field(monkeypatch):
                 monkeypatch.delenv(switch)
     finally:
         eng.close(); ix.close()
+
+
+def test_sparse_facet_field_of_a_squery_with_a_large_hit_bound(monkeypatch):
+    """A squery whose hit BOUND (hit_cap, from posting cardinalities: often far above the hit count) exceeds 131072 counts a
+    sparse single-valued field with per-hit atomics in k_docproc and selects over the touched bins; MGPU_FDIRECT_CAP lifts the
+    bound, and the rank kernel counts the field itself (k_facet_hash for few hits; for 135k hits the derived keys are
+    selected by k_select_mid: nothing else can derive them).  One shard of 300k documents, both routes and the plain
+    histogram route against the oracle and each other."""
+    import ctypes as C
+    from marlin_amd import ffi
+    lib = ffi.load()
+    V, S = 2048, 5
+    shards = [lib.msynth_zipf(300_000, V, 20_000, S, 0, 1)]
+    ix = Index.from_shards({}, shards, ["str"], ["num", "price"], ["flag"], ["cat", "hc"])
+    eng = GpuEngine(ix)
+    buf = C.create_string_buffer(16)
+
+    def word(r):
+        lib.msynth_zipf_word(V, S, r, buf)
+        return buf.value.decode()
+    try:
+        sizes = []
+        for q in ({"q": word(0), "rankBy": {"num": "desc"}, "maxFacetResults": 10, "fullScan": True},
+                  {"q": word(0) + " " + word(1) + " " + word(900)[:2], "maxFacetResults": 10, "fullScan": True},
+                  {"q": word(0)[:1] + " " + word(700), "rankBy": {"price": "asc"}, "maxFacetResults": 4, "fullScan": True},
+                  {"q": word(2), "maxFacetResults": 25, "fullScan": True}):
+            pq = ix.query(q)
+            g = eng.search(pq, capture=1)
+            o = orc_py.search(ix, pq, flags=1)
+            assert g["fullScan"], q
+            compare_results(g, o, ctx=q)
+            sizes.append(g["_shards"][0]["num_hits"])
+            for name, val in (("MGPU_FDIRECT_CAP", "8388608"), ("MGPU_NO_DIRECT_FACETS", "1"), ("MGPU_NO_HASH_FACETS", "1")):
+                monkeypatch.setenv(name, val)
+                g2 = eng.search(pq, capture=1)
+                monkeypatch.delenv(name)
+                assert [x["facets"] for x in g2["_shards"]] == [x["facets"] for x in g["_shards"]], (q, name)
+        assert max(sizes) > 131072 and min(sizes) < 8192, sizes
+    finally:
+        eng.close(); ix.close()
