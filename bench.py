@@ -88,8 +88,11 @@ def main():
                     help="multi-rank rehearsal on ONE GPU: gloo collectives on host tensors, every rank on cuda:0")
     ap.add_argument("--no-latency", action="store_true", help="skip the 200 single-query latency probes (cleaner kernel profiles)")
     ap.add_argument("--distinct", type=int, default=4096, help="distinct queries the stream cycles through")
-    ap.add_argument("--inflight", type=int, default=16, help="batches kept in flight per GPU (= contexts; one host thread per two contexts on one GPU)")
+    ap.add_argument("--inflight", type=int, default=None, help="batches kept in flight per GPU (= contexts; one host thread per two contexts on one GPU); "
+                    "default 16, or 8 above 20M documents (a context's arena grows with the shards' hit bounds: 16 of them do not fit beside a 31 GB mirror)")
     args = ap.parse_args()
+    if args.inflight is None:
+        args.inflight = 16 if args.docs <= 20_000_000 else 8
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
