@@ -22,7 +22,7 @@ typedef unsigned long long u64;
 
 extern "C" {
 void mgk_scatter(hipStream_t st, const ScatterItem *items, uint32_t nitems);
-void mgk_formula(hipStream_t st, const SqDev *sqs, const uint32_t *blob, uint32_t max_nblk, uint32_t nsq,
+void mgk_formula(hipStream_t st, const SqDev *sqs, const uint32_t *blob, uint32_t max_nblk, uint32_t nsq, uint32_t nmain,
                  uint2 *tile_list, uint32_t *tile_count, uint32_t tile_cap, uint32_t *fh_list, uint32_t *fh_count, uint32_t fh_cap);
 void mgk_rank(hipStream_t st, const SqDev *sqs, const uint32_t *blob, uint32_t max_n, uint32_t nsq,
               uint32_t max_tab_slots, int with_len, const uint2 *tile_list, const uint32_t *tile_count, uint32_t tile_cap,
@@ -31,7 +31,7 @@ void mgk_docproc(hipStream_t st, const SqDev *sqs, uint32_t nsq, const uint2 *ti
                  uint32_t tile_cap, uint32_t lds_bins, int pre);
 void mgk_fast_build(hipStream_t st, const SqDev *sqs, uint32_t nsq, const uint32_t *elig_list, uint32_t nelig,
                     uint2 *tile_list_b, uint32_t *tile_count_b);
-void mgk_facet_recount(hipStream_t st, const SqDev *sqs, const void *jobs, uint32_t njobs);
+void mgk_facet_recount(hipStream_t st, const SqDev *sqs, const void *jobs, uint32_t njobs, uint32_t max_k);
 void mgk_fkeys(hipStream_t st, const void *jobs, uint32_t njobs, uint32_t max_n);
 void mgk_card(hipStream_t st, const void *jobs, uint32_t njobs, uint32_t max_n);
 void mgk_check_zero(hipStream_t st, const void *p, size_t bytes, uint32_t *flag);
@@ -1534,6 +1534,7 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
             (void)tw;
             q.dbmap = (uint64_t *)(NZ + o.dbmap);
             q.fast_flag = &hdr->fast_flag; q.total_hits = &hdr->total_hits; q.num_rank = &hdr->num_rank;
+            sqd[o.aux_index].fast_flag = q.fast_flag;          // the twin looks at it too: no work for the twin of a squery that is not sampled
         }
         q.rows = (uint64_t *)(Z + o.rows);
         q.docid_map = o.docmap == (size_t)-1 ? nullptr : (uint64_t *)(NZ + o.docmap);
@@ -1625,11 +1626,12 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
                 !card_on_f && q.hit_cap <= fdirect_max_cap) {
                 q.fdirect_mask |= 1u << f;
                 sj.gen_touched = q.fac_ord[f]; sj.m_ptr = q.num_hits;
-                // ... and with few hits not even the histogram: k_facet_hash counts the ordinals in LDS
-                // (not for a squery that may be ranked on a sample: k_order files the hash jobs by the hit count BEFORE the
-                // sample replaces the hit list, the rank kernel and k_select_first look at the count AFTER it -- a sampled
-                // squery would fall between the two and nobody would count the field)
-                if (use_fhash && !q.fast_eligible && sj.k <= MG_FHASH_MAX_K && q.fhash_njobs < 4) {
+                // ... and with few hits not even the histogram: k_facet_hash counts the ordinals in LDS.  A squery that may
+                // be ranked on a sample is a hash job only when it turns out not to be sampled: k_order decides from the
+                // hit count, and the rank kernel and k_select_first read the flag it sets (fast_flag) -- until round 3's
+                // last day such squeries were simply no hash jobs, which cost the default mode its LDS path altogether.
+                if (use_fhash && sj.k <= MG_FHASH_MAX_K && q.fhash_njobs < 4) {
+                    sj.fast_flag = q.fast_eligible ? q.fast_flag : nullptr;
                     q.fhash_mask |= 1u << f; sj.fhash = 1; q.fhash_jobs[q.fhash_njobs++] = (uint32_t)j; nfhash++;
                 }
             }
@@ -1700,7 +1702,7 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
     mark();
     uint2 *d_tiles = (uint2 *)(NZ + off_tiles); uint32_t *d_tilecnt = (uint32_t *)(Z + off_tilecnt);
     uint32_t *d_fhlist = (uint32_t *)(NZ + off_fhlist), *d_fhcnt = (uint32_t *)(Z + off_fhcnt);
-    mgk_formula(st, d_sq, d_blob, max_nblk, (uint32_t)n_all, d_tiles, d_tilecnt, (uint32_t)tile_cap, d_fhlist, d_fhcnt, nfhash);
+    mgk_formula(st, d_sq, d_blob, max_nblk, (uint32_t)n_all, (uint32_t)n, d_tiles, d_tilecnt, (uint32_t)tile_cap, d_fhlist, d_fhcnt, nfhash);
     if (!elig_list.empty()) {
         // fast-rank (docrank.c:478-560): aggregations over ALL hits of the squeries k_order flagged, then their hit
         // lists become the samples and the work list is rebuilt
@@ -1726,7 +1728,7 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
     mgk_facet_hash(st, (const SelJob *)(UP + up_sel), UP + up_selout, d_fhlist, d_fhcnt, nfhash);
     mgk_select(st, (const SelJob *)(UP + up_sel), UP + up_selout, (uint32_t)seljobs.size(), max_selm, MG_SEL_PASSES, 0,
                NZ + off_items, sel_wide ? sel_cap_items : 0u, (uint32_t *)(Z + off_todocnt), (uint32_t *)(NZ + off_todo));
-    mgk_facet_recount(st, d_sq, UP + up_recount, (uint32_t)recount.size());
+    mgk_facet_recount(st, d_sq, UP + up_recount, (uint32_t)recount.size(), max_fac_k);
     mark();
     tick();
     if (copy_mode == 0) HIPCHK(hipMemcpyAsync(c->pin_out, R, res_bytes, hipMemcpyDeviceToHost, st));

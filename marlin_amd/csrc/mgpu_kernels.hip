@@ -142,6 +142,9 @@ __device__ __forceinline__ void emit_bits(u64 v, uint32_t base, uint32_t *hits, 
 // (five waves per SIMD is what the 31 KB of LDS allow; unbounded, the compiler takes 103 VGPRs for the loop and leaves four)
 __global__ __launch_bounds__(MG_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_formula(const SqDev *sqs, const uint32_t *blob, uint32_t run) {
     const SqDev *sp = &sqs[blockIdx.y];
+    // the zero-typo twin of a squery that is not going to be ranked on a sample (k_order of the squeries themselves has run
+    // and set the flag: mgk_formula): nobody reads its map or its count
+    if (sp->aux && sp->fast_flag && !*sp->fast_flag) return;
     const uint32_t nblk = sp->nblk;                                  // 256-word blocks of the row
     const uint32_t nwin = (nblk + MG_FORMULA_WORDS / MG_WORDS_PER_BLOCK - 1) / (MG_FORMULA_WORDS / MG_WORDS_PER_BLOCK);
     // A workgroup takes a run of consecutive windows: the descriptor, the plan and the descriptors of the first 256
@@ -338,6 +341,10 @@ __global__ __launch_bounds__(MG_BLOCK) void k_order(const SqDev *sqs, uint2 *til
     uint2 *win_info = sp->win_info;
     const uint32_t hit_cap = sp->hit_cap;
     uint32_t *p_err = sp->err, *p_num_hits = sp->num_hits;
+    if (sp->aux && sp->fast_flag && !*sp->fast_flag) {               // a twin k_formula skipped: no windows to add up
+        if (threadIdx.x == 0) *p_num_hits = 0;
+        return;
+    }
     __shared__ uint32_t lds[8];
     __shared__ uint32_t carry, s_tbase;
     if (threadIdx.x == 0) carry = 0;
@@ -370,7 +377,9 @@ __global__ __launch_bounds__(MG_BLOCK) void k_order(const SqDev *sqs, uint2 *til
             *sp->fast_flag = M > sp->fast_thresh ? 1u : 0u;
         }
     }
-    const uint32_t nfh = sp->fhash_njobs;
+    // (a squery that is about to be ranked on a sample is no hash job: its hit list is replaced, and the kernels that skip
+    // their own counting for hashed squeries -- the rank kernel, k_select_first -- test the same flag)
+    const uint32_t nfh = (sp->fast_eligible && M > sp->fast_thresh) ? 0u : sp->fhash_njobs;
     if (threadIdx.x < nfh && M <= MG_FHASH_MAX_M) {
         const uint32_t cls = M <= MG_FHASH_SMALL_M ? 0u : 1u;
         const uint32_t at = atomicAdd(&fh_count[cls], 1u);
@@ -548,7 +557,9 @@ __global__ __launch_bounds__(MG_BLOCK) void k_tiles_again(const SqDev *sqs, uint
 }
 
 // get_facet_totalcount (squery.c:398-408) for the facet lists of the fast-ranked squeries: the sampled count of every
-// listed id is replaced by |facetid2bmap[id, field] AND docid_map|.  One workgroup per (squery, field) list.
+// listed id is replaced by |facetid2bmap[id, field] AND docid_map|.  One workgroup per listed id (grid: lists x the
+// longest list of the batch): an id costs a binary search of dependent loads and a walk of its posting, and a list has
+// up to 2 * maxFacetResults of them -- one workgroup per list took 0.63 ms per batch of the default-mode stream.
 struct RecountJob { uint32_t sq; uint32_t field; u64 *out_hi; const u64 *out_lo; const uint32_t *out_n; };
 __global__ __launch_bounds__(MG_BLOCK) void k_facet_recount(const SqDev *sqs, const RecountJob *jobs) {
     const RecountJob j = jobs[blockIdx.x];
@@ -560,7 +571,7 @@ __global__ __launch_bounds__(MG_BLOCK) void k_facet_recount(const SqDev *sqs, co
     const uint32_t f = j.field, nord = sp->sh.fa_nord[f], W = sp->sh.W, Wp = sp->sh.Wp;
     const uint32_t *ord2id = sp->sh.fa_sorted_id[f];      // ids ascending: an id's position = its posting's offset from the field's base pid
     const u64 *D = (const u64 *)sp->docid_map;
-    for (uint32_t x = 0; x < n; x++) {
+    for (uint32_t x = blockIdx.y; x < n; x += gridDim.y) {
         const uint32_t id = (uint32_t)j.out_lo[x];
         uint32_t lo = 0, hi = nord;                                           // the id's place among the field's ids
         while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (ord2id[mid] < id) lo = mid + 1; else hi = mid; }
@@ -903,7 +914,9 @@ __global__ __launch_bounds__(MG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
         const KeyLayout kl = load_key_layout(sp);
         const double *col = sp->sh.num_col[rb >= 0 ? rb : 0];
         const int fac_here = sp->fac_in_rank;
-        const uint32_t fac_mask = sp->hist_mask, fdirect = sp->fdirect_mask, fhash = sp->fhash_mask;
+        const uint32_t fac_mask = sp->hist_mask, fdirect = sp->fdirect_mask;
+        uint32_t fhash = sp->fhash_mask;
+        if (fhash && sp->fast_eligible && *sp->fast_flag) fhash = 0;         // ranked on a sample: not a hash job (k_order)
         const int nfac = sp->sh.num_facets;
 #ifdef MGPU_CHECKED
         const uint32_t x_N = sp->sh.N, x_dw = sp->sh.dw_len, x_cap = sp->hit_cap, x_rec = sp->sh.rec_words;
@@ -2290,7 +2303,7 @@ __global__ __launch_bounds__(MG_BLOCK) void k_select_first(const SelJob *jobs, c
     __shared__ uint32_t s_scan[8], s_pcur[MG_SEL_DIGIT], s_runs[MG_SEL_DIGIT], s_misc[8];
     __shared__ u64 s_red[4 * MG_BLOCK / 64];
     DbgScope dbg_scope(13); dbg_scope.tag = M;
-    if (job.fhash && M <= MG_FHASH_MAX_M) return;                // k_facet_hash's job
+    if (job.fhash && M <= MG_FHASH_MAX_M && !(job.fast_flag && *job.fast_flag)) return;       // k_facet_hash's job (k_order filed it)
     if (M <= SEL_SMALL_CAP) {
         // short list: straight into the sort
         if (threadIdx.x == 0) { job.ctl[SEL_NIN] = M; job.ctl[SEL_KREM] = job.k; job.ctl[SEL_NFIN] = M; job.ctl[SEL_DONE] = 2u;
@@ -2740,15 +2753,23 @@ static uint32_t worklist_grid(uint32_t tile_cap) {
     if (g > tile_cap) g = tile_cap;
     return g ? g : 1;
 }
-void mgk_formula(hipStream_t st, const SqDev *sqs, const uint32_t *blob, uint32_t max_nblk, uint32_t nsq,
+// squeries [0, nmain) are the batch's own, [nmain, nsq) the zero-typo twins of those that may be ranked on a sample: the
+// twins run in a second pair of launches, after k_order has decided which squeries are sampled, and the others' return at once
+// (one squery in thirty of the default-mode bench stream is sampled; its twins used to double the formula stage)
+void mgk_formula(hipStream_t st, const SqDev *sqs, const uint32_t *blob, uint32_t max_nblk, uint32_t nsq, uint32_t nmain,
                  uint2 *tile_list, uint32_t *tile_count, uint32_t tile_cap, uint32_t *fh_list, uint32_t *fh_count, uint32_t fh_cap) {
     // runs of windows pay when the launch fills the chip several times over (-12 % on a 1024-squery batch); a lone query's
     // few hundred windows are better off side by side
     const uint32_t max_nwin = (max_nblk + 1) / 2;
     static const int forced = getenv("MGPU_FORMULA_RUN") ? atoi(getenv("MGPU_FORMULA_RUN")) : 0;     // tests: runs on small shards
-    const uint32_t run = forced > 0 ? (uint32_t)forced : (uint64_t)max_nwin * nsq >= 8192 ? MG_FORMULA_RUN : 1u;
-    hipLaunchKernelGGL(k_formula, dim3((max_nwin + run - 1) / run, nsq), dim3(MG_BLOCK), 0, st, sqs, blob, run);
-    hipLaunchKernelGGL(k_order, dim3(nsq), dim3(MG_BLOCK), 0, st, sqs, tile_list, tile_count, fh_list, fh_count, fh_cap);
+    if (nmain > nsq) nmain = nsq;
+    for (int part = 0; part < 2; part++) {
+        const uint32_t first = part ? nmain : 0u, cnt = part ? nsq - nmain : nmain;
+        if (!cnt) continue;
+        const uint32_t run = forced > 0 ? (uint32_t)forced : (uint64_t)max_nwin * cnt >= 8192 ? MG_FORMULA_RUN : 1u;
+        hipLaunchKernelGGL(k_formula, dim3((max_nwin + run - 1) / run, cnt), dim3(MG_BLOCK), 0, st, sqs + first, blob, run);
+        hipLaunchKernelGGL(k_order, dim3(cnt), dim3(MG_BLOCK), 0, st, sqs + first, tile_list, tile_count, fh_list, fh_count, fh_cap);
+    }
     hipLaunchKernelGGL(k_order_copy, dim3(worklist_grid(tile_cap)), dim3(MG_BLOCK), 0, st, sqs, tile_list, tile_count);
 }
 void mgk_fast_build(hipStream_t st, const SqDev *sqs, uint32_t nsq, const uint32_t *elig_list, uint32_t nelig,
@@ -2757,9 +2778,10 @@ void mgk_fast_build(hipStream_t st, const SqDev *sqs, uint32_t nsq, const uint32
     hipLaunchKernelGGL(k_fast_build, dim3(nelig), dim3(FB_NT), 0, st, sqs, elig_list);
     hipLaunchKernelGGL(k_tiles_again, dim3((nsq + MG_BLOCK - 1) / MG_BLOCK), dim3(MG_BLOCK), 0, st, sqs, nsq, tile_list_b, tile_count_b);
 }
-void mgk_facet_recount(hipStream_t st, const SqDev *sqs, const void *jobs, uint32_t njobs) {
+void mgk_facet_recount(hipStream_t st, const SqDev *sqs, const void *jobs, uint32_t njobs, uint32_t max_k) {
     if (!njobs) return;
-    hipLaunchKernelGGL(k_facet_recount, dim3(njobs), dim3(MG_BLOCK), 0, st, sqs, (const RecountJob *)jobs);
+    const uint32_t gy = max_k < 1 ? 1u : max_k > 64 ? 64u : max_k;         // (longer lists stride)
+    hipLaunchKernelGGL(k_facet_recount, dim3(njobs, gy), dim3(MG_BLOCK), 0, st, sqs, (const RecountJob *)jobs);
 }
 void mgk_rank(hipStream_t st, const SqDev *sqs, const uint32_t *blob, uint32_t max_n, uint32_t nsq,
               uint32_t max_tab_slots, int with_len, const uint2 *tile_list, const uint32_t *tile_count, uint32_t tile_cap,
