@@ -53,7 +53,7 @@ def zipf_word(lib, r):
     return buf.value.decode()
 
 
-def make_queries(lib, n, full_scan=True):
+def make_queries(lib, n, full_scan=True, variant=None):
     """3-word queries: two of the 24 most frequent words with one substituted letter (typo
     distance 1) + the first three letters of a frequent word (prefix -> twid posting)."""
     import random
@@ -67,8 +67,14 @@ def make_queries(lib, n, full_scan=True):
             c = rng.choice([ch for ch in "abcdefghijklmnopqrstuvwxyz" if ch != w[p]])
             ws.append(w[:p] + c + w[p + 1:])
         pre = zipf_word(lib, rng.randrange(0, 64))[:3]
-        qs.append({"q": " ".join(ws + [pre]), "fullScan": full_scan, "rankBy": {"num": "desc"},
-                   "hitsPerPage": 10, "maxFacetResults": 10})
+        q = {"q": " ".join(ws + [pre]), "fullScan": full_scan, "rankBy": {"num": "desc"},
+             "hitsPerPage": 10, "maxFacetResults": 10}
+        # side measurements (configs[3]'s ingredients on the bench stream; never the metric's configuration)
+        if variant == "filter":
+            q["filter"] = {"price": {"$lt": 300000}} if len(qs) % 2 else {"price": {"$gte": 300000}}
+        elif variant == "aggs":
+            q["aggs"] = {"a": {"avg": {"field": "price"}}, "s": {"stats": {"field": "num"}}, "c": {"cardinality": {"field": "cat"}}}
+        qs.append(q)
     return qs
 
 
@@ -92,6 +98,8 @@ def main():
                     "default 16, or 8 above 20M documents (a context's arena grows with the shards' hit bounds: 16 of them do not fit beside a 31 GB mirror)")
     ap.add_argument("--default-mode", action="store_true", help="NOT the metric's configuration: the reference's as-shipped mode (fullScan false): "
                     "shards with more than fullScanThreshold = 25000 hits are ranked on a sample (row f-3)")
+    ap.add_argument("--variant", choices=["filter", "aggs"], default=None, help="NOT the metric's configuration: the stream with a numeric range "
+                    "filter, or with avg / stats / cardinality aggregations (BASELINE configs[3]'s ingredients)")
     args = ap.parse_args()
     if args.inflight is None:
         args.inflight = 16 if args.docs <= 20_000_000 else 8
@@ -140,7 +148,7 @@ def main():
     nq_pool = max(B, args.distinct // B * B)   # distinct queries of the stream (rounds 1 and 2 cycled through the first 256
                                          # of the same generator; the mean hit count of a sample moves the rate: 18k there,
                                          # 28k over 4096)
-    pool = [ix.query(j) for j in make_queries(lib, nq_pool, full_scan=not args.default_mode)]
+    pool = [ix.query(j) for j in make_queries(lib, nq_pool, full_scan=not args.default_mode, variant=args.variant)]
     K_TOP, NF, FMAX, NAGG = 10, 2, 20, 0
     slot_b = lib.m_slot_bytes(K_TOP, NF, FMAX, NAGG)
 
@@ -418,7 +426,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "configs[2]: %d docs Zipf corpus, %d shards, 3-word typo+prefix query, 2 facet fields, "
-                                   "rankBy num desc, top-10, %s" % (args.docs, TOTAL_SHARDS, "DEFAULT MODE (fullScan false: not the metric's configuration)" if args.default_mode else "fullScan"),
+                                   "rankBy num desc, top-10, %s" % (args.docs, TOTAL_SHARDS, ("DEFAULT MODE (fullScan false: not the metric's configuration)" if args.default_mode else "fullScan") + (" + VARIANT %s (not the metric's configuration)" % args.variant if args.variant else "")),
                        "queries_per_step": B * S, "queries_per_device_batch": B, "device_batches_per_step": S, "batches_in_flight": F, "shards_per_gpu": local, "vocab": VOCAB,
                        "mean_hits_per_query": round(total_hits / max(1, args.steps * S * B), 1),
                        "distinct_queries": nq_pool, "plans_in_timed_region": bool(c_loop),

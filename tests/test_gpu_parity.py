@@ -141,6 +141,27 @@ def test_single_query_equals_batched(dg):
     assert all(x["ranks"] == a["ranks"] and x["facets"] == a["facets"] for x in b)
 
 
+def test_filter_rows_shared_within_a_batch_and_cardinality_sets_in_the_results(dg):
+    """The squeries of one shard that name the same filter operand (a sparse posting, a numeric range) share one scattered
+    row per batch; the id set of a cardinality aggregation over a small field comes back with the results download.  A batch
+    that repeats and mixes filters and aggregations must answer query by query like the queries run alone, and like the
+    oracle."""
+    ix, eng = dg
+    f1 = {"id": {"$lt": 4000}}
+    f2 = {"$or": [{"id": {"$gte": 7000}}, {"facetonly": "fourfour"}]}
+    f3 = {"$and": [{"id": {"$gte": 1000}}, {"id": {"$lt": 4000}}, {"facetonly": {"$ne": "threethree"}}]}
+    card = {"c": {"cardinality": {"field": "facetlist"}}, "s": {"stats": {"field": "num"}}}
+    jqs = [{"q": "aaaaaaa", "filter": f1}, {"q": "aaaaaab bbbbbbc", "filter": f1, "aggs": card}, {"q": "aa", "filter": f2},
+           {"q": "aaaaaaa bbbbbbb", "filter": f3, "aggs": card}, {"q": "", "filter": f1, "aggs": card}, {"q": "aaaaaaa", "filter": f2},
+           {"q": "bbbbbbb", "aggs": card}, {"q": "aaaaaaa", "filter": f3}]
+    pqs = [ix.query(dict(jq, fullScan=True, rankBy={"id": "desc"})) for jq in jqs]
+    together = eng.search(pqs, capture=3)
+    for pq, g in zip(pqs, together):
+        alone = eng.search(pq, capture=3)
+        assert g["ranks"] == alone["ranks"] and g["facets"] == alone["facets"] and repr(g.get("aggs")) == repr(alone.get("aggs")), pq.jq
+        compare_results(g, orc_py.search(ix, pq, flags=3), ctx=pq.jq)
+
+
 def test_long_position_lists_take_the_overflow_path():
     """documents whose matched words or positions exceed the LDS slices of the rank kernel
     (MG_MCAP matched words, MG_PCAP positions) are ranked by the overflow kernel"""
