@@ -24,6 +24,7 @@ typedef unsigned long long u64;
 
 extern "C" {
 void mgk_scatter(hipStream_t st, const ScatterItem *items, uint32_t nitems);
+void mgk_range_rows(hipStream_t st, const RangeRow *rows, uint32_t nrows, uint32_t max_w);
 void mgk_formula(hipStream_t st, const SqDev *sqs, const uint32_t *blob, uint32_t max_nblk, uint32_t nsq, uint32_t nmain,
                  uint2 *tile_list, uint32_t *tile_count, uint32_t tile_cap, uint32_t *fh_list, uint32_t *fh_count, uint32_t fh_cap);
 void mgk_rank(hipStream_t st, const SqDev *sqs, const uint32_t *blob, uint32_t max_n, uint32_t nsq,
@@ -955,6 +956,7 @@ struct SqHost {                          // host bookkeeping for one squery of t
 // ---- state of one batch between its launch (execute_begin) and its decode (execute_end); kept in the context
 // and reused from batch to batch, so that the vectors keep their capacity
 struct PendingScatter { int sq; int row; const uint32_t *src_dev; uint64_t n; };
+struct PendingRange { int sq; int row; int field; uint64_t lo, hi; };       // a range row built from the column (RangeRow)
 // a filter operand that is not a dense row (a sparse posting, a range of a num_dbi order) is scattered into a row of the batch's
 // zero region; the squeries of one shard that name the same operand share the row and the scatter
 struct RowKey {
@@ -1125,6 +1127,9 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
     Bump nz;           // non-zero region
     Bump cln;          // self-cleaned pool (its own allocation, see mgpu_ctx)
     std::vector<int> &nrows = P.nrows; nrows.assign(2 * (size_t)n, 0);
+    std::vector<PendingRange> prange;
+    std::vector<RangeRow> ranges;
+    const bool use_range_rows = !getenv("MGPU_NO_RANGE_ROWS");
     std::map<RowKey, int> rowmap;                    // filter operand -> row of its shard's pool
     std::map<const void *, int> pool_rows;           // rows per shard pool
     uint32_t max_nblk = 1, max_N = 1, max_pblocks = 1, max_fk = 1, max_selm = 1, max_tab = 1, max_fac_k = 0, max_fac_nord = 0, max_lds_bins = 0;
@@ -1287,8 +1292,14 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
                         if (it != rowmap.end()) row = it->second;
                         else {
                             row = pool_rows[sh]++; rowmap[key] = row;
-                            pscat.push_back({i, row, sd.np_doc[op.a] + op.lo, op.hi - op.lo});
-                            h.scatter_docs += op.hi - op.lo;
+                            // a long range of a single-valued field comes from the column (RangeRow), the rest is scattered
+                            if (use_range_rows && !((sh->np_multi >> op.a) & 1u) && (op.hi - op.lo) * MG_RANGE_ROW_FRACTION > sd.N) {
+                                prange.push_back({i, row, op.a, op.lo, op.hi});
+                                h.scatter_docs += 2ull * sd.N;                 // (8 B per document of the shard, in the scatter stage's 4-B units)
+                            } else {
+                                pscat.push_back({i, row, sd.np_doc[op.a] + op.lo, op.hi - op.lo});
+                                h.scatter_docs += op.hi - op.lo;
+                            }
                         }
                         a = ~row; depth++; h.formula_rows++;
                     } break;
@@ -1508,6 +1519,7 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
     size_t nitems = 0;
     for (auto &ps : pscat) nitems += (ps.n + MG_SCATTER_CHUNK - 1) / MG_SCATTER_CHUNK;
     const size_t up_items = up.take(std::max<size_t>(nitems, 1) * sizeof(ScatterItem));
+    const size_t up_ranges = up.take(std::max<size_t>(prange.size(), 1) * sizeof(RangeRow));
     const size_t up_sel = up.take(std::max<size_t>(seloff.size(), 1) * sizeof(SelJob));
     const size_t up_selout = up.take(std::max<size_t>(seloff.size(), 1) * sizeof(SelOut));
     size_t nfk = 0, ncard = 0;
@@ -1591,6 +1603,14 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
             it.n = (uint32_t)std::min<uint64_t>(MG_SCATTER_CHUNK, ps.n - at); it.pad = 0;
             items.push_back(it);
         }
+    }
+    uint32_t range_max_w = 0;
+    for (auto &pr : prange) {
+        SqDev &q = sqd[pr.sq];
+        RangeRow r; r.col = q.sh.num_col[pr.field]; r.dst = q.rows + (size_t)pr.row * q.sh.Wp; r.order = q.sh.np_doc[pr.field];
+        r.lo = pr.lo; r.hi = pr.hi; r.N = q.sh.N; r.W = q.sh.W;
+        ranges.push_back(r);
+        range_max_w = std::max(range_max_w, r.W);
     }
     // need_keys: the rank kernel has nothing to do when no hits are requested
     for (int i = 0; i < n; i++) if (!sqh[i].k) sqd[i].do_rank = -1;
@@ -1685,6 +1705,7 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
     if (!recount.empty()) memcpy(c->pin + up_recount, recount.data(), recount.size() * sizeof(RecountJob));
     if (!blob.empty()) memcpy(c->pin + up_blob, blob.data(), blob.size() * 4);
     if (!items.empty()) memcpy(c->pin + up_items, items.data(), items.size() * sizeof(ScatterItem));
+    if (!ranges.empty()) memcpy(c->pin + up_ranges, ranges.data(), ranges.size() * sizeof(RangeRow));
     if (!seljobs.empty()) { memcpy(c->pin + up_sel, seljobs.data(), seljobs.size() * sizeof(SelJob));
                             memcpy(c->pin + up_selout, selouts.data(), selouts.size() * sizeof(SelOut)); }
     if (!fkjobs.empty()) memcpy(c->pin + up_fk, fkjobs.data(), fkjobs.size() * sizeof(FkJob));
@@ -1727,6 +1748,7 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
     mark();
     tick();
     mgk_scatter(st, (const ScatterItem *)(UP + up_items), (uint32_t)items.size());
+    mgk_range_rows(st, (const RangeRow *)(UP + up_ranges), (uint32_t)ranges.size(), range_max_w);
     mark();
     uint2 *d_tiles = (uint2 *)(NZ + off_tiles); uint32_t *d_tilecnt = (uint32_t *)(Z + off_tilecnt);
     uint32_t *d_fhlist = (uint32_t *)(NZ + off_fhlist), *d_fhcnt = (uint32_t *)(Z + off_fhcnt);

@@ -96,6 +96,29 @@ __global__ __launch_bounds__(MG_BLOCK) void k_scatter(const ScatterItem *items, 
         scatter_chunk(s.src, s.n, (u64 *)s.dst);
     }
 }
+// RangeRow (mgpu_types.h): grid (x, rows); a wave takes 64 words = 4096 documents at a time, 64 coalesced loads of the
+// column per lane, one ballot each; lane i keeps word i.  Every word of the row below W is written (no zeroing needed).
+__global__ __launch_bounds__(MG_BLOCK) void k_range_rows(const RangeRow *rows) {
+    const RangeRow r = rows[blockIdx.y];
+    if (r.lo >= r.hi) return;
+    const uint32_t da = r.order[r.lo], db = r.order[r.hi - 1];
+    if (da >= r.N || db >= r.N) return;                               // (the mirror's own tables: cannot happen)
+    const double va = r.col[da], vb = r.col[db];
+    const double v_lo = va < vb ? va : vb, v_hi = va < vb ? vb : va;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * MG_BLOCK + threadIdx.x) >> 6, nwaves = gridDim.x * (MG_BLOCK / 64);
+    for (uint32_t wb = wave * 64; wb < r.W; wb += nwaves * 64) {      // wave-uniform
+        u64 mine = 0;
+#pragma unroll 8
+        for (uint32_t i = 0; i < 64; i++) {
+            const uint32_t d = (wb + i) * 64 + lane;
+            const double v = d < r.N ? r.col[d] : -1.7976931348623157e308;          // "no value" (get_num_value's marker)
+            const u64 m = __ballot(v >= v_lo && v <= v_hi);
+            if (lane == i) mine = m;
+        }
+        if (wb + lane < r.W) r.dst[wb + lane] = mine;
+    }
+}
 // the same for ONE list named by the kernel arguments (no item table to upload): chunks of MG_SCATTER_CHUNK docids
 __global__ __launch_bounds__(MG_BLOCK) void k_scatter_list(const uint32_t *src, uint64_t n, u64 *dst) {
     const uint64_t nchunks = (n + MG_SCATTER_CHUNK - 1) / MG_SCATTER_CHUNK;
@@ -2606,6 +2629,16 @@ void mgk_term_scan(hipStream_t st, const TermJob *jobs, const TermDict *dicts, u
     if (!ndicts || !max_words) return;
     hipLaunchKernelGGL(k_term_filter, dim3((max_words + MG_BLOCK - 1) / MG_BLOCK, ndicts), dim3(MG_BLOCK), 0, st, jobs, dicts, cand, counts + 1, cand_cap);
     hipLaunchKernelGGL(k_term_eval, dim3(1024), dim3(MG_BLOCK), 0, st, jobs, term_chars, (const uint2 *)cand, (const uint32_t *)(counts + 1), cand_cap, hits, counts, cap);
+}
+void mgk_range_rows(hipStream_t st, const RangeRow *rows, uint32_t nrows, uint32_t max_w) {
+    if (!nrows) return;
+    // 256 lanes = 4 waves = 256 words per workgroup and step; enough workgroups per row to cover it once, a few thousand in all
+    uint32_t gx = (max_w + 255) / 256; if (!gx) gx = 1;
+    const uint32_t cap = 8192 / (nrows < 8192 ? nrows : 8192); if (gx > cap) gx = cap ? cap : 1;
+    for (uint32_t at = 0; at < nrows; at += 65535) {
+        const uint32_t n = nrows - at < 65535 ? nrows - at : 65535;
+        hipLaunchKernelGGL(k_range_rows, dim3(gx, n), dim3(MG_BLOCK), 0, st, rows + at);
+    }
 }
 void mgk_scatter(hipStream_t st, const ScatterItem *items, uint32_t nitems) {
     if (!nitems) return;

@@ -193,6 +193,12 @@ struct SqDev {
     uint32_t *err;                   // device word, nonzero = MGPU_E_* (negated)
 };
 
+// a numeric-range filter operand built from the field's column (one value per document: ShardDev::num_col) instead of
+// scattered from its sorted docid list: positions [lo, hi) of the num_dbi order are the documents whose value lies between
+// the values at the two ends of the range (the host cut the range at value boundaries), so the row is one coalesced pass
+// over the column -- 8 B per document of the shard, where the scatter costs an atomic per docid of the range
+struct RangeRow { const double *col; uint64_t *dst; const uint32_t *order; uint64_t lo, hi; uint32_t N, W; };
+#define MG_RANGE_ROW_FRACTION 14u    // a range of more than N / 14 docids is built from the column (27G scattered docids/s against 375G column values/s)
 struct ScatterItem {                 // one chunk of a sorted docid list OR-ed into a scratch row
     const uint32_t *src;
     uint64_t *dst;
