@@ -74,6 +74,18 @@ def make_queries(lib, n, full_scan=True, variant=None):
             q["filter"] = {"price": {"$lt": 300000}} if len(qs) % 2 else {"price": {"$gte": 300000}}
         elif variant == "filter-distinct":                       # no two queries of the stream share their range
             q["filter"] = {"price": {"$lt": 200000 + 97 * len(qs)}} if len(qs) % 2 else {"price": {"$gte": 200000 + 97 * len(qs)}}
+        elif variant == "strfilter":                              # a facet value as filter (cat has 64 values)
+            q["filter"] = {"cat": "cat%02d" % (len(qs) % 64)}
+        elif variant == "facets-only":
+            q["hitsPerPage"] = 0
+        elif variant == "page":                                   # third page of 100 hits
+            q["hitsPerPage"] = 100; q["page"] = 3
+        elif variant == "words1":
+            q["q"] = ws[0]
+        elif variant == "words4":
+            q["q"] = " ".join(ws + [zipf_word(lib, rng.randrange(0, 24)), pre])
+        elif variant == "sort":
+            del q["rankBy"]; q["sortBy"] = {"price": "asc"}
         elif variant == "aggs":
             q["aggs"] = {"a": {"avg": {"field": "price"}}, "s": {"stats": {"field": "num"}}, "c": {"cardinality": {"field": "cat"}}}
         qs.append(q)
@@ -100,7 +112,7 @@ def main():
                     "default 16, or 8 above 20M documents (a context's arena grows with the shards' hit bounds: 16 of them do not fit beside a 31 GB mirror)")
     ap.add_argument("--default-mode", action="store_true", help="NOT the metric's configuration: the reference's as-shipped mode (fullScan false): "
                     "shards with more than fullScanThreshold = 25000 hits are ranked on a sample (row f-3)")
-    ap.add_argument("--variant", choices=["filter", "filter-distinct", "aggs"], default=None, help="NOT the metric's configuration: the stream with a numeric range "
+    ap.add_argument("--variant", choices=["filter", "filter-distinct", "aggs", "strfilter", "facets-only", "page", "words1", "words4", "sort"], default=None, help="NOT the metric's configuration: the stream with a numeric range "
                     "filter, or with avg / stats / cardinality aggregations (BASELINE configs[3]'s ingredients)")
     args = ap.parse_args()
     if args.inflight is None:

@@ -909,7 +909,22 @@ static int ensure_arena(mgpu_ctx *c, size_t bytes) {
     if (c->arena.dev) HIPCHK(hipFree(c->arena.dev));
     size_t cap = std::max(bytes + bytes / 4, (size_t)(16u << 20));
     c->arena.dev = nullptr; c->arena.cap = 0;
-    HIPCHK(hipMalloc((void **)&c->arena.dev, cap));
+    // The arena of a batch is sized by the squeries' hit BOUNDS (about 60 bytes per possible hit and squery: hit lists,
+    // keys, per-hit facet ordinals), and every context in flight holds its own: a batch of one-word queries that may match
+    // half of a 10M-document index wants tens of GB.  No room: first without the growth margin, then a limit the caller can
+    // act on (fewer queries per batch, or fewer contexts in flight) -- the context stays usable for a smaller batch.
+    if (hipMalloc((void **)&c->arena.dev, cap) != hipSuccess) {
+        (void)hipGetLastError();
+        c->arena.dev = nullptr; cap = bytes;
+        if (hipMalloc((void **)&c->arena.dev, cap) != hipSuccess) {
+            (void)hipGetLastError();
+            c->arena.dev = nullptr;
+            char msg[200];
+            snprintf(msg, sizeof(msg), "the batch needs %.1f GB of device scratch (hit bounds of its squeries) and the device has no room: fewer queries per batch or fewer contexts in flight",
+                     (double)bytes / 1e9);
+            return fail(MGPU_E_LIMIT, msg);
+        }
+    }
     c->arena.cap = cap;
     return MGPU_OK;
 }
