@@ -1690,11 +1690,12 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
                 q.fdirect_mask |= 1u << f;
                 sj.gen_touched = q.fac_ord[f]; sj.m_ptr = q.num_hits;
                 // ... and with few hits not even the histogram: k_facet_hash counts the ordinals in LDS.  A squery that may
-                // be ranked on a sample is a hash job only when it turns out not to be sampled: k_order decides from the
-                // hit count, and the rank kernel and k_select_first read the flag it sets (fast_flag) -- until round 3's
-                // last day such squeries were simply no hash jobs, which cost the default mode its LDS path altogether.
-                if (use_fhash && sj.k <= MG_FHASH_MAX_K && q.fhash_njobs < 4) {
-                    sj.fast_flag = q.fast_eligible ? q.fast_flag : nullptr;
+                // be ranked on a sample (fast_eligible) qualifies when its threshold is at least MG_FHASH_MAX_M: "few enough hits
+                // for hashing" then implies "not sampled", so k_order (which files the job by the hit count BEFORE a sample
+                // replaces the list) and the kernels that skip their own counting for hashed squeries (they see the count
+                // AFTER it) cannot disagree.  With a lower threshold a sampled squery would fall between the two and nobody
+                // would count the field (found in round 3): no hash jobs for such a squery.
+                if (use_fhash && (!q.fast_eligible || q.fast_thresh >= MG_FHASH_MAX_M) && sj.k <= MG_FHASH_MAX_K && q.fhash_njobs < 4) {
                     q.fhash_mask |= 1u << f; sj.fhash = 1; q.fhash_jobs[q.fhash_njobs++] = (uint32_t)j; nfhash++;
                 }
             }

@@ -400,9 +400,9 @@ __global__ __launch_bounds__(MG_BLOCK) void k_order(const SqDev *sqs, uint2 *til
             *sp->fast_flag = M > sp->fast_thresh ? 1u : 0u;
         }
     }
-    // (a squery that is about to be ranked on a sample is no hash job: its hit list is replaced, and the kernels that skip
-    // their own counting for hashed squeries -- the rank kernel, k_select_first -- test the same flag)
-    const uint32_t nfh = (sp->fast_eligible && M > sp->fast_thresh) ? 0u : sp->fhash_njobs;
+    // (a squery that may be ranked on a sample names hash jobs only when its threshold is at least MG_FHASH_MAX_M -- the host's
+    // rule: "few enough hits for hashing" then implies "not sampled", for this kernel, the rank kernel and k_select_first alike)
+    const uint32_t nfh = sp->fhash_njobs;
     if (threadIdx.x < nfh && M <= MG_FHASH_MAX_M) {
         const uint32_t cls = M <= MG_FHASH_SMALL_M ? 0u : 1u;
         const uint32_t at = atomicAdd(&fh_count[cls], 1u);
@@ -937,9 +937,7 @@ __global__ __launch_bounds__(MG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
         const KeyLayout kl = load_key_layout(sp);
         const double *col = sp->sh.num_col[rb >= 0 ? rb : 0];
         const int fac_here = sp->fac_in_rank;
-        const uint32_t fac_mask = sp->hist_mask, fdirect = sp->fdirect_mask;
-        uint32_t fhash = sp->fhash_mask;
-        if (fhash && sp->fast_eligible && *sp->fast_flag) fhash = 0;         // ranked on a sample: not a hash job (k_order)
+        const uint32_t fac_mask = sp->hist_mask, fdirect = sp->fdirect_mask, fhash = sp->fhash_mask;
         const int nfac = sp->sh.num_facets;
 #ifdef MGPU_CHECKED
         const uint32_t x_N = sp->sh.N, x_dw = sp->sh.dw_len, x_cap = sp->hit_cap, x_rec = sp->sh.rec_words;
@@ -2326,7 +2324,7 @@ __global__ __launch_bounds__(MG_BLOCK) void k_select_first(const SelJob *jobs, c
     __shared__ uint32_t s_scan[8], s_pcur[MG_SEL_DIGIT], s_runs[MG_SEL_DIGIT], s_misc[8];
     __shared__ u64 s_red[4 * MG_BLOCK / 64];
     DbgScope dbg_scope(13); dbg_scope.tag = M;
-    if (job.fhash && M <= MG_FHASH_MAX_M && !(job.fast_flag && *job.fast_flag)) return;       // k_facet_hash's job (k_order filed it)
+    if (job.fhash && M <= MG_FHASH_MAX_M) return;                // k_facet_hash's job
     if (M <= SEL_SMALL_CAP) {
         // short list: straight into the sort
         if (threadIdx.x == 0) { job.ctl[SEL_NIN] = M; job.ctl[SEL_KREM] = job.k; job.ctl[SEL_NFIN] = M; job.ctl[SEL_DONE] = 2u;

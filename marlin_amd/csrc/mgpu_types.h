@@ -93,7 +93,6 @@ struct SelJob {                      // one top-k selection (rank keys of a sque
     // hash table straight from the hits' ordinals whenever the squery has at most MG_FHASH_MAX_M hits: no histogram
     // is touched then (the rank kernel skips its atomics, k_select_first skips the job)
     uint32_t fhash;
-    const uint32_t *fast_flag;       // SqDev::fast_flag of a squery that may be ranked on a sample (then it is no hash job after all), else NULL
 };
 #define MG_FHASH_SMALL_M 1536u       // ... of which the 256-lane / 4096-slot size of k_facet_hash takes those up to here
 #define MG_FHASH_MAX_M 8192u         // most hits for which a sparse facet field is counted by hashing in LDS
