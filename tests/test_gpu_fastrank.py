@@ -97,7 +97,7 @@ def test_fast_rank_with_a_sparse_single_valued_facet_field(monkeypatch):
     kernel -- or, for squeries of few hits, by hashing the hits' ordinals (k_facet_hash).  k_order files the hash jobs by
     the hit count BEFORE a sample replaces the hit list; the kernels that skip their own counting for hashed squeries look
     at the count AFTER it.  A sampled squery used to fall between the two and came back with an empty facet list (found in
-    round 3): such squeries are no hash jobs any more.  The sample's counts of a 20000-value field are ties nearly
+    round 3): a squery whose threshold lies below the hash jobs' reach (as here: 5000 < 8192) names no hash jobs any more.  The sample's counts of a 20000-value field are ties nearly
     everywhere, so which values are listed is the canonical choice, not the reference's (ties): the lists are
     checked for what must hold whatever the choice -- every listed count is the EXACT number of matching documents with
     that value (the recount, squery.c:398-408), in descending order -- and against the other counting paths."""
