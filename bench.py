@@ -11,12 +11,17 @@ launches of --batch queries each, --inflight of them in flight.
   N = 1 : all 8 shards on one GPU.
   N > 1 : shards split over the ranks (8/N each; the corpus is fixed but the queries per step grow with N, so a rank's work per step is constant => weak scaling); every rank runs
           the whole query batch on its shards, per-shard result slots are exchanged with ONE RCCL
-          all_gather (torch.distributed over xGMI) and every rank merges its share of the queries.
+          all_gather (ncclAllGather issued from the C serving loop, mgpu_comm_*; torch.distributed only hands the RCCL id round)
+          and every rank merges its share of the queries.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant
 kernel stage (HIP-event timed on the launch stream) and `cpu_baseline` (the C oracle = port of the
 reference's CPU path run as the reference runs it: a thread pool over (query, shard) jobs on the host's cores,
 bounded sample).
+
+Side measurements, never the metric's configuration (the line's config.workload says so): --default-mode (fullScan false: shards
+above fullScanThreshold hits ranked on a sample), --variant filter | filter-distinct | aggs | strfilter | facets-only | page |
+words1 | words4 | sort (the stream with one ingredient changed: DESIGN.md (d)), --docs 50000000 (configs[4]).
 """
 import argparse
 import ctypes as C
