@@ -2515,6 +2515,8 @@ __global__ void k_clock_cal(unsigned long long *out) {
 // sizes it needs.
 #define TF_TERMS 256
 #define TF_WBUF 512                                  // candidates a wave collects in LDS before it takes a range of the global list
+#define TF_WORDS 4                                   // words per lane: the ~25 instructions of loop, LDS read and broadcast per (wave, term)
+                                                     // are most of this kernel; four words share them
 __global__ __launch_bounds__(MG_BLOCK) void k_term_filter(const TermJob *jobs, const TermDict *dicts, uint2 *cand, uint32_t *count, uint32_t cap) {
     __shared__ uint2 s_t[TF_TERMS];                  // {tsig, maxdist | prefix << 8}
     // One counter for the whole list, bumped by every wave that found something, serialises the chip on one address
@@ -2524,10 +2526,13 @@ __global__ __launch_bounds__(MG_BLOCK) void k_term_filter(const TermJob *jobs, c
     __shared__ uint2 s_buf[MG_BLOCK / 64][TF_WBUF];
     const TermDict *dp = &dicts[blockIdx.y];
     const uint32_t nwords = dp->nwords, job_lo = dp->job_lo, job_hi = dp->job_hi;
-    if (blockIdx.x * MG_BLOCK >= nwords) return;
-    const uint32_t w = blockIdx.x * MG_BLOCK + threadIdx.x;
-    const bool valid = w < nwords;
-    const uint32_t wsig = valid ? dp->sig[w] : 0u;
+    if (blockIdx.x * (MG_BLOCK * TF_WORDS) >= nwords) return;
+    uint32_t w[TF_WORDS], wsig[TF_WORDS];
+#pragma unroll
+    for (int u = 0; u < TF_WORDS; u++) {
+        w[u] = (blockIdx.x * TF_WORDS + u) * MG_BLOCK + threadIdx.x;
+        wsig[u] = w[u] < nwords ? dp->sig[w[u]] : 0u;
+    }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     uint2 *buf = s_buf[wv];
     uint32_t n = 0;                                  // entries in buf: the same value in every lane of the wave (ballots)
@@ -2547,13 +2552,16 @@ __global__ __launch_bounds__(MG_BLOCK) void k_term_filter(const TermJob *jobs, c
         __syncthreads();
         for (uint32_t i = 0; i < nt; i++) {
             const uint2 t = s_t[i];
-            const bool pass = valid & mg_lev_sig_pass(t.x, (int)(t.y & 0xFF), (int)(t.y >> 8), wsig);
-            const u64 m = __ballot(pass);
-            if (!m) continue;
-            const uint32_t add = (uint32_t)__popcll(m);
-            if (n + add > TF_WBUF) { flush(); n = 0; }
-            if (pass) buf[n + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = make_uint2(j0 + i, w);
-            n += add;
+#pragma unroll
+            for (int u = 0; u < TF_WORDS; u++) {
+                const bool pass = (w[u] < nwords) & mg_lev_sig_pass(t.x, (int)(t.y & 0xFF), (int)(t.y >> 8), wsig[u]);
+                const u64 m = __ballot(pass);
+                if (!m) continue;
+                const uint32_t add = (uint32_t)__popcll(m);
+                if (n + add > TF_WBUF) { flush(); n = 0; }
+                if (pass) buf[n + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = make_uint2(j0 + i, w[u]);
+                n += add;
+            }
         }
     }
     if (n) flush();
@@ -2625,7 +2633,7 @@ int mgk_debug_phases(int on, unsigned long long *out16) {
 void mgk_term_scan(hipStream_t st, const TermJob *jobs, const TermDict *dicts, uint32_t ndicts, uint32_t max_words, const uint32_t *term_chars,
                    uint2 *cand, uint32_t cand_cap, uint32_t *hits, uint32_t *counts, uint32_t cap) {
     if (!ndicts || !max_words) return;
-    hipLaunchKernelGGL(k_term_filter, dim3((max_words + MG_BLOCK - 1) / MG_BLOCK, ndicts), dim3(MG_BLOCK), 0, st, jobs, dicts, cand, counts + 1, cand_cap);
+    hipLaunchKernelGGL(k_term_filter, dim3((max_words + MG_BLOCK * TF_WORDS - 1) / (MG_BLOCK * TF_WORDS), ndicts), dim3(MG_BLOCK), 0, st, jobs, dicts, cand, counts + 1, cand_cap);
     hipLaunchKernelGGL(k_term_eval, dim3(1024), dim3(MG_BLOCK), 0, st, jobs, term_chars, (const uint2 *)cand, (const uint32_t *)(counts + 1), cand_cap, hits, counts, cap);
 }
 void mgk_range_rows(hipStream_t st, const RangeRow *rows, uint32_t nrows, uint32_t max_w) {
