@@ -1897,7 +1897,7 @@ __device__ __forceinline__ void select_solo(const SelJob &job, const SelOut &out
 // minimum is <= T: at most k * R keys survive the cut "key <= T", and the top k are among them.  One pass for the
 // minima, a counting rank over 256 minima in LDS (no barriers inside), one pass for the survivors, then the small sort.
 // The order is (hi, lo, index) as everywhere in this file, so ties resolve to the lowest docid / facet id.
-// Requires k <= 256 < M and k * R <= SEL_SMALL_CAP (checked by the caller).
+// Requires k <= NT < M and k * R <= SEL_SMALL_CAP (checked by the caller).
 // Rank of this lane's key (h, l, i) among the NT lanes' keys when it is one of the k smallest, else some number >= k.
 // Keys must differ between lanes.  Two levels: every wave ranks its 64 keys with lane broadcasts (no LDS), the min(k, 64)
 // smallest of each wave -- the only ones that can be among the k smallest overall -- meet in LDS and are ranked against
@@ -2357,7 +2357,7 @@ __global__ __launch_bounds__(MG_BLOCK) void k_select_first(const SelJob *jobs, c
         }
         return;
     }
-    if (M <= SEL_SOLO_CHUNKS * SEL_CHUNK && job.k <= MG_SEL_SOLO_K && job.k * ((M + MG_BLOCK - 1) / MG_BLOCK) <= SEL_SMALL_CAP && L.lanemin) {
+    if (M <= SEL_SOLO_CHUNKS * SEL_CHUNK && job.k <= MG_BLOCK && job.k * ((M + MG_BLOCK - 1) / MG_BLOCK) <= SEL_SMALL_CAP && L.lanemin) {
         // (hist doubles as the minima's LDS: 3 x 256 words of key + 256 of index fit its 2048 words)
         select_lanemin<MG_BLOCK>(job, out, M, (u64 *)hist, (u64 *)hist + MG_BLOCK, hist + 4 * MG_BLOCK, s_misc, s_fhi, s_flo, s_fix, s_fcnt);
         return;
@@ -2505,8 +2505,8 @@ __global__ void k_clock_cal(unsigned long long *out) {
 }
 // ------------------------------------------------------------------ f-1: term lookup
 // dtrie_lookup_term's typo walk (dtrie.c:710-791) as a scan in two steps.
-// k_term_filter: blockIdx.y = dictionary, blockIdx.x = 256-word chunk of it; every lane holds ONE word's 4-byte
-// signature (mg_lev.h: character classes + length) and tests it against every term of the call that reads this
+// k_term_filter: blockIdx.y = dictionary, blockIdx.x = 1024-word chunk of it; every lane holds the 4-byte signatures
+// (mg_lev.h: character classes + length) of FOUR words and tests them against every term of the call that reads this
 // dictionary (term signatures staged in LDS, read as broadcasts): ~10 instructions per (term, word) pair instead of the
 // walk's several hundred.  The pairs that pass -- a necessary condition, about 1 in 100 -- go to a candidate list with
 // one atomic per wave.

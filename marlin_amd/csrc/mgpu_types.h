@@ -101,7 +101,7 @@ struct SelJob {                      // one top-k selection (rank keys of a sque
 #define MG_FAC_LOOKUP 0xFFFFFFFEu     // fac_ord: several values, or not staged: k_docproc reads the record / CSR itself
 #define MG_SEL_MID_KEYS 131072u      // longest fresh list one 1024-thread workgroup selects (k_select_mid)
 #define MG_FDIRECT_MAX_CAP MG_SEL_MID_KEYS // largest hit bound (SqDev::hit_cap) of a squery whose sparse single-valued field is counted from the rank kernel
-#define MG_SEL_SOLO_K 256u           // largest k of the one-workgroup selections
+#define MG_SEL_SOLO_K 512u           // largest k of the one-workgroup selections (= MG_SEL_SMALL: their final set is ranked in LDS)
 #define MG_CARD_IN_RES 4096u         // a cardinality aggregation over a field of at most this many values returns its id set in the results region
 // ctl words
 enum { SEL_NCAND, SEL_KREM, SEL_NWIN, SEL_DONE, SEL_TICKET, SEL_NEXT, SEL_BITPOS, SEL_PASS, SEL_WORDS = 16 };

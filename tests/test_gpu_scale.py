@@ -58,6 +58,25 @@ def test_large_hit_lists_match_oracle(zipf):
     assert big > 32768, "corpus too small to reach the multi-workgroup select"
 
 
+def test_deep_pages_around_the_one_workgroup_selection_bound(zipf):
+    """k = page x hitsPerPage on either side of MG_SEL_SOLO_K = 512 (the largest k one workgroup selects by itself;
+    256 until round 3, when a third page of 100 hits went through three wide launches), over lists of under 8192 hits
+    (k_select_first), up to 131072 (k_select_mid) and beyond (the wide launches), ranked by a number and by position (ties)"""
+    lib, ix, eng = zipf
+    w0, w1, w40, w300 = word(lib, 0), word(lib, 1), word(lib, 40), word(lib, 300)
+    qs, sizes = [], set()
+    for text in (w300, w40, w0 + " " + w1, ""):
+        for hpp, page in ((257, 1), (100, 3), (128, 4), (171, 3), (500, 1), (100, 6)):
+            qs.append({"q": text, "hitsPerPage": hpp, "page": page, "maxHits": 1000, "rankBy": {"num": "desc"}})
+        qs.append({"q": text, "hitsPerPage": 100, "page": 5, "maxHits": 1000})
+    pqs = [ix.query(dict(jq, fullScan=True)) for jq in qs]
+    got = eng.search(pqs, capture=3)
+    for pq, g in zip(pqs, got):
+        compare_results(g, orc_py.search(ix, pq, flags=3), ctx=pq.jq)
+        sizes.update(s["num_hits"] for s in g["_shards"])
+    assert min(sizes) < 8192 and any(8192 < n <= 131072 for n in sizes) and max(sizes) > 131072, sorted(sizes)
+
+
 def test_result_independent_of_batching(zipf):
     lib, ix, eng = zipf
     pqs = [ix.query(dict(jq, fullScan=True)) for jq in queries(lib)]
