@@ -1627,6 +1627,8 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
         ranges.push_back(r);
         range_max_w = std::max(range_max_w, r.W);
     }
+    // rows of one column next to each other: a group of them shares the column's loads (k_range_rows)
+    std::stable_sort(ranges.begin(), ranges.end(), [](const RangeRow &a, const RangeRow &b) { return (uintptr_t)a.col < (uintptr_t)b.col; });
     // need_keys: the rank kernel has nothing to do when no hits are requested
     for (int i = 0; i < n; i++) if (!sqh[i].k) sqd[i].do_rank = -1;
     // facet counting rides on the rank kernel's record visit whenever that kernel reads the records

@@ -77,6 +77,30 @@ def test_deep_pages_around_the_one_workgroup_selection_bound(zipf):
     assert min(sizes) < 8192 and any(8192 < n <= 131072 for n in sizes) and max(sizes) > 131072, sorted(sizes)
 
 
+def test_batch_of_distinct_numeric_ranges_on_two_fields(zipf, monkeypatch):
+    """wide numeric ranges become filter rows built from the column (k_range_rows), four rows of one column per workgroup
+    sharing the column's loads: a batch whose ranges all differ, on two fields and in counts that leave ragged groups,
+    against the oracle and against the rows scattered from the sorted order (MGPU_NO_RANGE_ROWS)"""
+    lib, ix, eng = zipf
+    w0 = word(lib, 0)
+    for nq in (1, 5, 11):
+        jqs = []
+        for i in range(nq):
+            f = {"price": {"$gte": 1000 + 37 * i, "$lt": 400000 + 50021 * i}} if i % 3 != 2 else {"num": {"$gt": 50 + i, "$lte": 90000 + 17001 * i}}
+            if i == 4:
+                f = {"$and": [f, {"num": {"$gte": 20000}}]}                  # two rows of different columns in one squery
+            jqs.append({"q": w0 if i % 2 else "", "filter": f, "rankBy": {"num": "desc"}, "fullScan": True})
+        pqs = [ix.query(jq) for jq in jqs]
+        got = eng.search(pqs, capture=3)
+        monkeypatch.setenv("MGPU_NO_RANGE_ROWS", "1")
+        plain = eng.search(pqs, capture=3)
+        monkeypatch.delenv("MGPU_NO_RANGE_ROWS")
+        for pq, g, p2 in zip(pqs, got, plain):
+            assert g["ranks"] == p2["ranks"] and g["totalHits"] == p2["totalHits"] and g["facets"] == p2["facets"], pq.jq
+            compare_results(g, orc_py.search(ix, pq, flags=3), ctx=pq.jq)
+        assert all(g["totalHits"] > 0 for g in got)
+
+
 def test_result_independent_of_batching(zipf):
     lib, ix, eng = zipf
     pqs = [ix.query(dict(jq, fullScan=True)) for jq in queries(lib)]
