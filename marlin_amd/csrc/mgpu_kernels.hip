@@ -100,8 +100,10 @@ __global__ __launch_bounds__(MG_BLOCK) void k_scatter(const ScatterItem *items, 
 // coalesced loads of the column per lane, one ballot each; lane i keeps word i.  Every word of the row below W is written (no
 // zeroing needed).  Rows of one group that read the SAME column (the host lists the rows by column: a batch of queries
 // with a range each on one field) share its loads: the column is read once per group, not once per row -- the rows
-// of a batch re-read it from L2 / the memory-side cache otherwise, and that traffic was the kernel (0.90 ms per 1024 rows).
-#define MG_RANGE_GROUP 4
+// of a batch re-read it from L2 / the memory-side cache otherwise, and that traffic was the kernel (0.90 ms per 1024 rows;
+// 0.38 ms with groups of eight, where the two compares and the two selects per (word, row) are what is left: groups of 16
+// read 0.40 ms).
+#define MG_RANGE_GROUP 8
 __device__ __forceinline__ bool range_row_bounds(const RangeRow &r, double *v_lo, double *v_hi) {
     if (r.lo >= r.hi) return false;
     const uint32_t da = r.order[r.lo], db = r.order[r.hi - 1];
@@ -2683,11 +2685,14 @@ void mgk_term_scan(hipStream_t st, const TermJob *jobs, const TermDict *dicts, u
 }
 void mgk_range_rows(hipStream_t st, const RangeRow *rows, uint32_t nrows, uint32_t max_w) {
     if (!nrows) return;
-    // 256 lanes = 4 waves = 256 words per workgroup and step; enough workgroups per group of rows to cover it once, a few
-    // thousand in all
+    // A wave takes 64 words per step, a workgroup 256.  As many workgroups per group of rows as cover the row in the fewest
+    // steps the budget of ~16k workgroups allows, and no more than that many steps need: every wave then runs the same
+    // number of steps (64 workgroups over a row of 305 wave-steps left half the waves a second step to wait for)
     const uint32_t ngroups = (nrows + MG_RANGE_GROUP - 1) / MG_RANGE_GROUP;
-    uint32_t gx = (max_w + 255) / 256; if (!gx) gx = 1;
-    const uint32_t cap = 8192 / (ngroups < 8192 ? ngroups : 8192); if (gx > cap) gx = cap ? cap : 1;
+    const uint32_t nw64 = (max_w + 63) / 64 ? (max_w + 63) / 64 : 1;
+    const uint32_t gx_cap = 16384 / (ngroups < 16384 ? ngroups : 16384) ? 16384 / (ngroups < 16384 ? ngroups : 16384) : 1;
+    const uint32_t steps = (nw64 + 4 * gx_cap - 1) / (4 * gx_cap);
+    const uint32_t gx = (nw64 + 4 * steps - 1) / (4 * steps);
     for (uint32_t at = 0; at < ngroups; at += 65535) {
         const uint32_t n = ngroups - at < 65535 ? ngroups - at : 65535;
         hipLaunchKernelGGL(k_range_rows, dim3(gx, n), dim3(MG_BLOCK), 0, st, rows + (size_t)at * MG_RANGE_GROUP, nrows - at * MG_RANGE_GROUP);

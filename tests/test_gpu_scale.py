@@ -78,7 +78,7 @@ def test_deep_pages_around_the_one_workgroup_selection_bound(zipf):
 
 
 def test_batch_of_distinct_numeric_ranges_on_two_fields(zipf, monkeypatch):
-    """wide numeric ranges become filter rows built from the column (k_range_rows), four rows of one column per workgroup
+    """wide numeric ranges become filter rows built from the column (k_range_rows), eight rows of one column per workgroup
     sharing the column's loads: a batch whose ranges all differ, on two fields and in counts that leave ragged groups,
     against the oracle and against the rows scattered from the sorted order (MGPU_NO_RANGE_ROWS)"""
     lib, ix, eng = zipf
