@@ -1486,9 +1486,14 @@ __global__ __launch_bounds__(64) void k_aggfinal(const SqDev *sqs, int pre) {
     const uint32_t tiles = (M + MG_BLOCK - 1) / MG_BLOCK;
     const uint32_t nact = tiles < sq.nproc_blocks ? tiles : sq.nproc_blocks;
     AggPart p = {0.0, 1.7976931348623157e308, -1.7976931348623157e308, 0};
-    for (uint32_t b = 0; b < nact; b++) {
-        const AggPart q = sq.agg_part[(size_t)b * sq.num_aggs + a];
-        p.sum += q.sum; p.mn = q.mn < p.mn ? q.mn : p.mn; p.mx = q.mx > p.mx ? q.mx : p.mx; p.cnt += q.cnt;
+    // (eight partials loaded ahead, combined in the same order: the walk is one lane's chain of dependent loads otherwise)
+    for (uint32_t b0 = 0; b0 < nact; b0 += 8) {
+        AggPart q[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++) if (b0 + u < nact) q[u] = sq.agg_part[(size_t)(b0 + u) * sq.num_aggs + a];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++)
+            if (b0 + u < nact) { p.sum += q[u].sum; p.mn = q[u].mn < p.mn ? q[u].mn : p.mn; p.mx = q[u].mx > p.mx ? q[u].mx : p.mx; p.cnt += q[u].cnt; }
     }
     sq.agg_out[a] = p;
 }
