@@ -5,7 +5,9 @@ declared in marlin_amd/host/*.h and include/marlin_gpu.h.  The structures below 
 marlin_amd/host/mcommon.h field for field; sizes are verified against the library at import.
 """
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
@@ -208,6 +210,12 @@ def load():
     if not os.path.exists(path):
         raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "or `make` in the repo root" % path)
+    # PyTorch ships ROCm runtime libraries of its own.  A process that loads this library first (against /opt/rocm) and
+    # imports torch afterwards runs with parts of both and aborts when it exits ("double free or corruption"; found with
+    # tools/phase_probe.py in round 3); the other order shares one runtime.  Nothing in this package calls torch -- it is
+    # the N > 1 plumbing of bench.py and of tests -- so it is imported first only where it is installed and not loaded yet.
+    if "torch" not in sys.modules and importlib.util.find_spec("torch") is not None:
+        import torch  # noqa: F401
     # the GPU library first, so the dependency resolves without an rpath lookup surprise
     C.CDLL(os.path.join(LIB_DIR, "libmarlin_gpu.so"), mode=C.RTLD_GLOBAL)
     lib = C.CDLL(path, mode=C.RTLD_GLOBAL)

@@ -54,3 +54,16 @@ def test_product_path_fails_loudly_without_a_gpu():
             GpuEngine(ix)
     finally:
         ix.close()
+
+
+def test_loading_the_library_puts_torch_first_where_it_is_installed():
+    """PyTorch ships ROCm runtime libraries of its own; a process that loads libmarlin_gpu.so (linked against /opt/rocm)
+    and imports torch AFTERWARDS aborts when it exits (found in round 3).  ffi.load() therefore imports torch first where
+    it is installed: a fresh interpreter must have it in sys.modules once the library is loaded."""
+    import importlib.util
+    import subprocess
+    import sys
+    if importlib.util.find_spec("torch") is None:
+        pytest.skip("torch is not installed")
+    code = "import sys; from marlin_amd import ffi; assert 'torch' not in sys.modules; ffi.load(); assert 'torch' in sys.modules"
+    subprocess.run([sys.executable, "-c", code], cwd=ROOT, check=True, timeout=300)

@@ -52,3 +52,5 @@ gpu.mgk_debug_clock_cal.argtypes = [C.POINTER(C.c_ulonglong)]
 gpu.mgk_debug_clock_cal(cal)
 print("clock cal: wall ticks %d, shader cycles %d, event ns %d" % (cal[0], cal[1], cal[2]))
 print("select kernel span (first WG start -> last WG end): %.1f us" % ((v[15] - ((~v[14]) & 0xFFFFFFFFFFFFFFFF)) / 100))
+eng.free_prepared(prep)
+eng.close(); ix.close()
