@@ -1149,6 +1149,7 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
     std::map<const void *, int> pool_rows;           // rows per shard pool
     uint32_t max_nblk = 1, max_N = 1, max_pblocks = 1, max_fk = 1, max_selm = 1, max_tab = 1, max_fac_k = 0, max_fac_nord = 0, max_lds_bins = 0;
     bool sel_wide = false;            // some selection may need the wide (many-workgroup) passes or the stand-alone sorts
+    size_t sel_items = 1;             // workgroups those selections can ask for in one wide launch
 
     std::vector<Offs> &offs = P.offs; offs.resize(2 * (size_t)n);
     std::vector<SelOff> &seloff = P.seloff; seloff.clear();
@@ -1479,7 +1480,7 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
             so.hist = cln.take(MG_SEL_BINS * 4); so.ctl = zer.take(SEL_WORDS * 4); so.outidx = nz.take((size_t)MG_SEL_FINAL * 4);
             seloff.push_back(so); jobfix.push_back({i, 0, 0});
             max_selm = std::max(max_selm, q.hit_cap);
-            if (q.hit_cap > MG_SEL_MID_KEYS || h.k > MG_SEL_SOLO_K) sel_wide = true;
+            if (q.hit_cap > MG_SEL_MID_KEYS || h.k > MG_SEL_SOLO_K) { sel_wide = true; sel_items += std::min<size_t>(64, ((size_t)q.hit_cap + 2047) / 2048); }
         }
         for (int j = 0; j < h.nfac; j++) {
             int f = h.fac_field[j];
@@ -1491,7 +1492,9 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
             seloff.push_back(so); jobfix.push_back({i, 1, j});
             max_selm = std::max(max_selm, so.mcap);
             // (a field counted straight from the rank kernel is selected over one key per hit)
-            if (std::max(so.mcap, q.hit_cap) > MG_SEL_MID_KEYS || h.fac_k[j] > MG_SEL_SOLO_K) sel_wide = true;
+            if (std::max(so.mcap, q.hit_cap) > MG_SEL_MID_KEYS || h.fac_k[j] > MG_SEL_SOLO_K) {
+                sel_wide = true; sel_items += std::min<size_t>(64, ((size_t)std::max(so.mcap, q.hit_cap) + 2047) / 2048);
+            }
         }
     }
     // batch-wide work list of hit tiles, filled by k_order
@@ -1507,9 +1510,11 @@ static int execute_begin(mgpu_ctx_t *c, mgpu_shard_t *const *shards, const mgpu_
     const size_t off_todo = nz.take(2 * (seloff.size() + 1) * 4);                         // final list, mid list
     const size_t off_fhcnt = zer.take(2 * 4, 8);                                          // k_facet_hash job lists: counters ...
     const size_t off_fhlist = nz.take(2 * (seloff.size() + 1) * 4);                       // ... and the two lists
-    // a job never asks for more than min(64, ceil(capacity / 2048)) workgroups per wide launch
-    size_t sel_items = 1;
-    for (const SelOff &so : seloff) sel_items += std::min<size_t>(64, ((size_t)so.mcap + 2047) / 2048);
+    // A job never asks for more than min(64, ceil(capacity / 2048)) workgroups per wide launch, and only the jobs counted
+    // above can ask at all (the others finish in k_select_first / k_select_mid): the lists, and with them the grids of
+    // the wide launches, are sized for those (the bench stream, where the hit BOUNDS of a few dozen squeries per batch
+    // exceed one workgroup's reach, still fills the 2048 workgroups a wide launch is capped at: no change there).  Should
+    // a job find no room all the same, the host-driven rounds pick it up.
     const uint32_t sel_cap_items = (uint32_t)sel_items;
     const size_t off_items = nz.take((size_t)sel_cap_items * 4 * sizeof(uint2));
     // scratch rows (zero region), now that row counts are known
