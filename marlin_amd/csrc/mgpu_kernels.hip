@@ -1337,9 +1337,10 @@ __global__ __launch_bounds__(MG_BLOCK) void k_rank_overflow(const SqDev *sqs, co
 // squeries whose fast_flag is set (calculate_agg over all matching documents, docrank.c:553-557); 0 = the normal pass,
 // in which those squeries count facets only (perform_doc_processing, docrank.c:409).
 #define DP_ITEMS 256                         // work items a workgroup looks at at a time
+#define DP_AGGS 2                            // aggregations reduced together per pass over a slice
 __global__ __launch_bounds__(MG_BLOCK) void k_docproc(const SqDev *sqs, const uint2 *tile_list, const uint32_t *tile_count, uint32_t lds_bins, int pre) {
     uint32_t *hist = (uint32_t *)dyn_tab;        // lds_bins words of dynamic LDS: the largest field of the batch that is privatised
-    __shared__ AggPart red[MG_BLOCK / 64];
+    __shared__ AggPart red[DP_AGGS][MG_BLOCK / 64];
     __shared__ uint2 s_items[DP_ITEMS];
     const uint32_t ntiles = *tile_count;
     // A workgroup takes a run of consecutive work items: a squery's items sit together on the list (k_order), so the
@@ -1430,42 +1431,67 @@ __global__ __launch_bounds__(MG_BLOCK) void k_docproc(const SqDev *sqs, const ui
                 }
             }
 
-            for (uint32_t x = x0; x < x1 && naggs > 0; x++) {
+            // Aggregations: DP_AGGS of them per pass over the slice -- one load of the hit, the values of all of them in
+            // flight together, one barrier pair -- where each used to make a pass of its own (the slices of the bench
+            // stream are one or two hits per lane: the passes were dependent-load latencies in a row).  Per aggregation
+            // the order of additions is what it was: the lane's hits in order, the fixed lane tree, the waves in order.
+            // (fast && !pre: aggregated before the sample replaced the hit list)
+            for (uint32_t x = x0; x < x1 && naggs > 0 && !(fast && !pre); x++) {
                 const uint32_t vb = __builtin_amdgcn_readfirstlane(s_items[x].y);
                 if (vb >= nvb) continue;
-                for (int a = 0; a < naggs; a++) {
-                    if (sq.agg_type[a] == MGPU_A_CARDINALITY) continue;
-                    if (fast && !pre) continue;                  // aggregated before the sample replaced the hit list
-                    const uint32_t af = (uint32_t)sq.agg_field[a];
-                    const uint64_t *grp = fast ? sq.sh.grp_has[af] : nullptr;    // fast mode reads idnum2dbl: a missing group = no value
-                    const double *col = sq.sh.num_col[af];
-                    const bool in_rec = af < nnum_in;
-                    double sum = 0.0, mn = 1.7976931348623157e308, mx = -1.7976931348623157e308;
-                    unsigned long long cnt = 0;
+                for (int a0 = 0; a0 < naggs; a0 += DP_AGGS) {
+                    double sum[DP_AGGS], mn[DP_AGGS], mx[DP_AGGS];
+                    unsigned long long cnt[DP_AGGS];
+                    const double *col[DP_AGGS]; const uint64_t *grp[DP_AGGS];
+                    uint32_t af[DP_AGGS]; bool live[DP_AGGS], in_rec[DP_AGGS];
+#pragma unroll
+                    for (int u = 0; u < DP_AGGS; u++) {
+                        const int a = a0 + u;
+                        live[u] = a < naggs && sq.agg_type[a] != MGPU_A_CARDINALITY;
+                        af[u] = live[u] ? (uint32_t)sq.agg_field[a] : 0u;
+                        col[u] = live[u] ? sq.sh.num_col[af[u]] : nullptr;
+                        grp[u] = (live[u] && fast) ? sq.sh.grp_has[af[u]] : nullptr;  // fast mode reads idnum2dbl: a missing group = no value
+                        in_rec[u] = af[u] < nnum_in;
+                        sum[u] = 0.0; mn[u] = 1.7976931348623157e308; mx[u] = -1.7976931348623157e308; cnt[u] = 0;
+                    }
                     for (uint32_t i = vb * MG_BLOCK + threadIdx.x; i < M; i += stride) {
                         const uint32_t d = hits[i];
-                        const double v = in_rec ? *(const double *)(rec + (size_t)d * S4 + 4 + 2 * af) : col[d];
-                        if (grp && !((grp[(d / 1000u) >> 6] >> ((d / 1000u) & 63u)) & 1ull)) continue;
-                        if (v != -1.7976931348623157e308) {          // get_num_value's "no value" marker, metric-aggs.c:106,149
-                            sum += v; mn = v < mn ? v : mn; mx = v > mx ? v : mx; cnt++;
+                        double v[DP_AGGS];
+#pragma unroll
+                        for (int u = 0; u < DP_AGGS; u++)
+                            v[u] = !live[u] ? -1.7976931348623157e308 : in_rec[u] ? *(const double *)(rec + (size_t)d * S4 + 4 + 2 * af[u]) : col[u][d];
+#pragma unroll
+                        for (int u = 0; u < DP_AGGS; u++) {
+                            if (!live[u]) continue;
+                            if (grp[u] && !((grp[u][(d / 1000u) >> 6] >> ((d / 1000u) & 63u)) & 1ull)) continue;
+                            if (v[u] != -1.7976931348623157e308) {       // get_num_value's "no value" marker, metric-aggs.c:106,149
+                                sum[u] += v[u]; mn[u] = v[u] < mn[u] ? v[u] : mn[u]; mx[u] = v[u] > mx[u] ? v[u] : mx[u]; cnt[u]++;
+                            }
                         }
                     }
                     // fixed-shape tree: lanes, then waves, so the f64 sum is reproducible run to run
 #pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) {
-                        const double s2 = __shfl_down(sum, o, 64), n2 = __shfl_down(mn, o, 64), x2 = __shfl_down(mx, o, 64);
-                        const unsigned long long c2 = __shfl_down(cnt, o, 64);
-                        sum += s2; mn = n2 < mn ? n2 : mn; mx = x2 > mx ? x2 : mx; cnt += c2;
-                    }
-                    if ((threadIdx.x & 63) == 0) { AggPart p = {sum, mn, mx, cnt}; red[threadIdx.x >> 6] = p; }
-                    __syncthreads();
-                    if (threadIdx.x == 0) {
-                        AggPart p = red[0];
-                        for (int w2 = 1; w2 < MG_BLOCK / 64; w2++) {
-                            p.sum += red[w2].sum; p.mn = red[w2].mn < p.mn ? red[w2].mn : p.mn;
-                            p.mx = red[w2].mx > p.mx ? red[w2].mx : p.mx; p.cnt += red[w2].cnt;
+                    for (int u = 0; u < DP_AGGS; u++) {
+                        if (!live[u]) continue;                       // workgroup-uniform
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) {
+                            const double s2 = __shfl_down(sum[u], o, 64), n2 = __shfl_down(mn[u], o, 64), x2 = __shfl_down(mx[u], o, 64);
+                            const unsigned long long c2 = __shfl_down(cnt[u], o, 64);
+                            sum[u] += s2; mn[u] = n2 < mn[u] ? n2 : mn[u]; mx[u] = x2 > mx[u] ? x2 : mx[u]; cnt[u] += c2;
                         }
-                        sq.agg_part[(size_t)vb * naggs + a] = p;
+                        if ((threadIdx.x & 63) == 0) { AggPart p = {sum[u], mn[u], mx[u], cnt[u]}; red[u][threadIdx.x >> 6] = p; }
+                    }
+                    __syncthreads();
+                    if (threadIdx.x < DP_AGGS) {
+                        const int a = a0 + (int)threadIdx.x;
+                        if (a < naggs && sq.agg_type[a] != MGPU_A_CARDINALITY) {
+                            AggPart p = red[threadIdx.x][0];
+                            for (int w2 = 1; w2 < MG_BLOCK / 64; w2++) {
+                                const AggPart q = red[threadIdx.x][w2];
+                                p.sum += q.sum; p.mn = q.mn < p.mn ? q.mn : p.mn; p.mx = q.mx > p.mx ? q.mx : p.mx; p.cnt += q.cnt;
+                            }
+                            sq.agg_part[(size_t)vb * naggs + a] = p;
+                        }
                     }
                     __syncthreads();
                 }
